@@ -1,0 +1,478 @@
+// ff_api.cpp — the C ABI (include/firefly/ff_api.h): tracer state, scene upload, frame rendering, HIP-GL pixel-buffer
+// interop and measurement.  Host side of the seam the reference has at kernel.cu:268-298 (upload) and
+// kernel.cu:335-344 (per-frame map -> clear -> kernel -> unmap).
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+// (the interop header relies on hip_runtime.h having been included first)
+#include <hip/hip_gl_interop.h>
+
+#include "ff_internal.h"
+#include "ff_kernels.h"
+
+using namespace ff;
+
+struct FfState {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    // scene (device)
+    GeomRecord* d_geoms = nullptr;
+    TriRecord* d_tris = nullptr;
+    BvhNode* d_nodes = nullptr;
+    int num_geoms = 0, num_nodes = 0, max_depth = 0;
+    uint64_t num_tris = 0;
+    bool has_scene = false;
+    // work buffers (device)
+    float* d_accum = nullptr;
+    size_t accum_bytes = 0;
+    unsigned char* d_rgb8 = nullptr;
+    size_t rgb8_bytes = 0;
+    float* d_radiance = nullptr;
+    size_t radiance_bytes = 0;
+    unsigned* d_queue = nullptr;
+    unsigned long long* d_counters = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool collect_stats = false;
+    FfStats stats;
+    // GL interop
+    hipGraphicsResource* pbo_resource = nullptr;
+    int pbo_width = 0, pbo_height = 0;
+};
+
+namespace {
+
+#define FF_HIP(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (call);                                                                               \
+        if (_e != hipSuccess) return fail(FF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+void free_scene(FfState* s)
+{
+    if (s->d_geoms) (void)hipFree(s->d_geoms);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    s->d_geoms = nullptr;
+    s->d_tris = nullptr;
+    s->d_nodes = nullptr;
+    s->has_scene = false;
+    s->num_geoms = s->num_nodes = s->max_depth = 0;
+    s->num_tris = 0;
+}
+
+int ensure_bytes(void** ptr, size_t* cap, size_t need)
+{
+    if (*cap >= need && *ptr) return FF_OK;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(ptr, need);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FF_ERR_OOM : FF_ERR_HIP, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    *cap = need;
+    return FF_OK;
+}
+
+int check_params(const FfRenderParams* p)
+{
+    if (!p) return fail(FF_ERR_INVALID_ARG, "render params are null");
+    if (p->width <= 0 || p->height <= 0) return fail(FF_ERR_INVALID_ARG, "image size %dx%d is invalid", p->width, p->height);
+    if ((uint64_t)p->width * (uint64_t)p->height >= (1ull << 31)) return fail(FF_ERR_INVALID_ARG, "image too large");
+    if (p->bounces < 1 || p->bounces > 255) return fail(FF_ERR_INVALID_ARG, "bounces must be in 1..255 (got %d)", p->bounces);
+    if (p->spp < 1 || p->spp >= (1 << 24)) return fail(FF_ERR_INVALID_ARG, "spp must be in 1..2^24-1 (got %d)", p->spp);
+    if (p->trace_mode != FF_TRACE_BRUTE_FORCE && p->trace_mode != FF_TRACE_BVH) return fail(FF_ERR_INVALID_ARG, "unknown trace_mode %d", p->trace_mode);
+    if (p->shade_mode != FF_SHADE_NORMAL_DEBUG && p->shade_mode != FF_SHADE_DIFFUSE_PATH) return fail(FF_ERR_INVALID_ARG, "unknown shade_mode %d", p->shade_mode);
+    if (p->grid_mode != FF_GRID_FULL && p->grid_mode != FF_GRID_REFERENCE_FLOOR) return fail(FF_ERR_INVALID_ARG, "unknown grid_mode %d", p->grid_mode);
+    if (p->spp_per_launch < 0) return fail(FF_ERR_INVALID_ARG, "spp_per_launch must be >= 0");
+    return FF_OK;
+}
+
+// Core of every render entry point.  rgb8_dev / radiance_dev are device pointers to the LOCAL image (local_rows x W).
+int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, int strip_rows, int part, int num_parts, int local_rows,
+                 unsigned char* rgb8_dev, float* radiance_dev)
+{
+    const int W = prm->width, H = prm->height;
+    const size_t local_pixels = (size_t)local_rows * (size_t)W;
+    s->stats = FfStats();
+    if (local_pixels == 0) return FF_OK;
+
+    const bool debug = prm->shade_mode == FF_SHADE_NORMAL_DEBUG;
+    const int spp = debug ? 1 : prm->spp;
+    const int bounces = debug ? 1 : prm->bounces;
+    int chunk = (prm->spp_per_launch > 0 && !debug) ? prm->spp_per_launch : spp;
+    if (chunk > spp) chunk = spp;
+    const int launches = (spp + chunk - 1) / chunk;
+    if (launches > 1) {
+        int st = ensure_bytes((void**)&s->d_accum, &s->accum_bytes, local_pixels * 4 * sizeof(float));
+        if (st != FF_OK) return st;
+    }
+
+    KParams k;
+    std::memset(&k, 0, sizeof k);
+    FfMat4 cm;
+    ff_camera_ray_matrix(camera, &cm);
+    std::memcpy(k.cam_c0, &cm.m[0], 16);
+    std::memcpy(k.cam_c1, &cm.m[4], 16);
+    std::memcpy(k.cam_c2, &cm.m[8], 16);
+    std::memcpy(k.cam_c3, &cm.m[12], 16);
+    k.cam_pos[0] = camera->m_position.x;
+    k.cam_pos[1] = camera->m_position.y;
+    k.cam_pos[2] = camera->m_position.z;
+    k.far_clip = camera->m_farClip;
+    k.screen_w = camera->m_screenWidth;
+    k.screen_h = camera->m_screenHeight;
+    k.width = W;
+    k.height = H;
+    k.xlim = W;
+    k.ylim = H;
+    if (prm->grid_mode == FF_GRID_REFERENCE_FLOOR) { // kernel.cu:306-309
+        k.xlim = (W / 16) * 16;
+        k.ylim = (H / 16) * 16;
+    }
+    k.strip_rows = strip_rows;
+    k.part = part;
+    k.num_parts = num_parts;
+    k.local_rows = local_rows;
+    k.tiles_per_row = (W + 7) / 8;
+    const uint64_t tiles = (uint64_t)k.tiles_per_row * (uint64_t)((local_rows + 7) / 8);
+    if (tiles * 64 >= (1ull << 32)) return fail(FF_ERR_INVALID_ARG, "image too large for the work queue");
+    k.total_items = (unsigned)(tiles * 64);
+    k.bounces = bounces;
+    k.spp_total = spp;
+    k.key = (unsigned)prm->seed ^ (unsigned)(prm->seed >> 32);
+    k.shade_mode = prm->shade_mode;
+    k.num_geoms = s->num_geoms;
+    k.geoms = s->d_geoms;
+    k.tris = s->d_tris;
+    k.nodes = s->d_nodes;
+    k.stack_depth = s->max_depth + 2;
+    k.lds_nodes = s->num_nodes < max_lds_nodes(k.stack_depth) ? s->num_nodes : max_lds_nodes(k.stack_depth);
+    if (k.lds_nodes < 0) k.lds_nodes = 0;
+    k.accum = s->d_accum;
+    k.rgb8 = rgb8_dev;
+    k.radiance = radiance_dev;
+    k.queue = s->d_queue;
+    k.counters = s->d_counters;
+
+    const int blocks_per_cu = prm->trace_mode == FF_TRACE_BVH ? 1 : 2;
+    int grid = s->num_cus * blocks_per_cu;
+    const uint64_t max_useful = (k.total_items + (uint64_t)kBlockThreads - 1) / (uint64_t)kBlockThreads;
+    if ((uint64_t)grid > max_useful) grid = (int)max_useful;
+    if (grid < 1) grid = 1;
+
+    hipStream_t st = s->stream;
+    // cudaMemset(pbo, 0) of kernel.cu:340: untraced and missed pixels read 0
+    if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
+    if (radiance_dev) FF_HIP(hipMemsetAsync(radiance_dev, 0, local_pixels * 3 * sizeof(float), st));
+    FF_HIP(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), st));
+    FF_HIP(hipEventRecord(s->ev_begin, st));
+    for (int l = 0; l < launches; ++l) {
+        k.spp_begin = l * chunk;
+        k.spp_end = (l + 1) * chunk < spp ? (l + 1) * chunk : spp;
+        k.first_chunk = l == 0;
+        k.last_chunk = l == launches - 1;
+        FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
+        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, st));
+    }
+    FF_HIP(hipEventRecord(s->ev_end, st));
+    FF_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    FF_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
+    unsigned long long c[8];
+    FF_HIP(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    s->stats.rays_traced = c[0];
+    s->stats.nodes_visited = c[1];
+    s->stats.tris_tested = c[2];
+    s->stats.planes_tested = c[3];
+    s->stats.kernel_ms = ms;
+    s->stats.kernel_launches = (uint32_t)launches;
+    s->stats.scene_bytes_nodes = (uint64_t)s->num_nodes * sizeof(BvhNode);
+    s->stats.scene_bytes_tris = s->num_tris * sizeof(TriRecord);
+    return FF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ff_create(FfState** out_state, int device_id)
+{
+    clear_error();
+    if (!out_state) return fail(FF_ERR_INVALID_ARG, "ff_create: out_state is null");
+    *out_state = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(FF_ERR_NO_DEVICE, "ff_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(FF_ERR_INVALID_ARG, "ff_create: device %d out of range (0..%d)", device_id, count - 1);
+    FF_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    FF_HIP(hipGetDeviceProperties(&prop, device_id));
+    FfState* s = new (std::nothrow) FfState();
+    if (!s) return fail(FF_ERR_OOM, "ff_create: out of host memory");
+    s->device = device_id;
+    s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t pe = prepare_kernels();
+    if (pe != hipSuccess) {
+        delete s;
+        return fail(FF_ERR_HIP, "ff_create: kernel preparation failed: %s (is this a gfx950 device?)", hipGetErrorString(pe));
+    }
+    if (hipMalloc((void**)&s->d_queue, 64) != hipSuccess || hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
+        ff_destroy(s);
+        return fail(FF_ERR_HIP, "ff_create: allocating work buffers failed");
+    }
+    *out_state = s;
+    return FF_OK;
+}
+
+int ff_destroy(FfState* s)
+{
+    if (!s) return FF_OK;
+    (void)hipSetDevice(s->device);
+    if (s->pbo_resource) (void)hipGraphicsUnregisterResource(s->pbo_resource);
+    free_scene(s);
+    if (s->d_accum) (void)hipFree(s->d_accum);
+    if (s->d_rgb8) (void)hipFree(s->d_rgb8);
+    if (s->d_radiance) (void)hipFree(s->d_radiance);
+    if (s->d_queue) (void)hipFree(s->d_queue);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
+    if (s->ev_end) (void)hipEventDestroy(s->ev_end);
+    delete s;
+    return FF_OK;
+}
+
+int ff_set_stream(FfState* s, void* hip_stream)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_set_stream: state is null");
+    s->stream = (hipStream_t)hip_stream;
+    return FF_OK;
+}
+
+int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_upload_scene: state is null");
+    CompiledScene cs;
+    BvhBuildParams bp;
+    int st = compile_scene(host_geometries, n, bp, cs);
+    if (st != FF_OK) return st;
+    FF_HIP(hipSetDevice(s->device));
+    free_scene(s);
+    // One allocation + one copy per array (the reference issues a cudaMallocManaged + two cudaMemcpy per geometry, kernel.cu:277-298).
+    FF_HIP(hipMalloc((void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
+    FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
+    // Keep the triangle / node arrays non-null so the kernels can form addresses even for plane-only scenes.
+    const size_t tri_bytes = (cs.tris.size() ? cs.tris.size() : 1) * sizeof(TriRecord);
+    const size_t node_bytes = (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(BvhNode);
+    FF_HIP(hipMalloc((void**)&s->d_tris, tri_bytes));
+    FF_HIP(hipMalloc((void**)&s->d_nodes, node_bytes));
+    if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
+    if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    s->num_geoms = (int)cs.geoms.size();
+    s->num_nodes = (int)cs.nodes.size();
+    s->num_tris = cs.tris.size();
+    s->max_depth = cs.max_depth;
+    s->has_scene = true;
+    return FF_OK;
+}
+
+int ff_strips_local_rows(int height, int strip_rows, int part, int num_parts)
+{
+    if (height <= 0 || strip_rows <= 0 || num_parts <= 0 || part < 0 || part >= num_parts) return 0;
+    const int nstrips = (height + strip_rows - 1) / strip_rows;
+    int rows = 0;
+    for (int sidx = part; sidx < nstrips; sidx += num_parts) {
+        const int y0 = sidx * strip_rows;
+        rows += (y0 + strip_rows <= height) ? strip_rows : height - y0;
+    }
+    return rows;
+}
+
+int ff_render_strips(FfState* s, const FfCamera* camera, const FfRenderParams* params, int strip_rows, int part, int num_parts, void* rgb8,
+                     int rgb8_on_device, float* radiance, int radiance_on_device, int* out_local_rows)
+{
+    clear_error();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render: state is null");
+    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render: camera is null");
+    int st = check_params(params);
+    if (st != FF_OK) return st;
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render: no scene uploaded");
+    if (strip_rows <= 0 || num_parts <= 0 || part < 0 || part >= num_parts) return fail(FF_ERR_INVALID_ARG, "ff_render_strips: bad strip partition (%d rows, part %d of %d)", strip_rows, part, num_parts);
+    FF_HIP(hipSetDevice(s->device));
+    const int local_rows = ff_strips_local_rows(params->height, strip_rows, part, num_parts);
+    if (out_local_rows) *out_local_rows = local_rows;
+    const size_t local_pixels = (size_t)local_rows * (size_t)params->width;
+
+    unsigned char* rgb8_dev = nullptr;
+    float* rad_dev = nullptr;
+    if (rgb8) {
+        if (rgb8_on_device) rgb8_dev = (unsigned char*)rgb8;
+        else {
+            st = ensure_bytes((void**)&s->d_rgb8, &s->rgb8_bytes, local_pixels * 3 + 16);
+            if (st != FF_OK) return st;
+            rgb8_dev = s->d_rgb8;
+        }
+    }
+    if (radiance) {
+        if (radiance_on_device) rad_dev = radiance;
+        else {
+            st = ensure_bytes((void**)&s->d_radiance, &s->radiance_bytes, local_pixels * 3 * sizeof(float) + 16);
+            if (st != FF_OK) return st;
+            rad_dev = s->d_radiance;
+        }
+    }
+    st = render_local(s, camera, params, strip_rows, part, num_parts, local_rows, rgb8_dev, rad_dev);
+    if (st != FF_OK) return st;
+    if (rgb8 && !rgb8_on_device && local_pixels) FF_HIP(hipMemcpy(rgb8, rgb8_dev, local_pixels * 3, hipMemcpyDeviceToHost));
+    if (radiance && !radiance_on_device && local_pixels) FF_HIP(hipMemcpy(radiance, rad_dev, local_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FF_OK;
+}
+
+int ff_render(FfState* s, const FfCamera* camera, const FfRenderParams* params, void* rgb8, int rgb8_on_device, float* radiance,
+              int radiance_on_device)
+{
+    const int h = params ? params->height : 1;
+    return ff_render_strips(s, camera, params, h > 0 ? h : 1, 0, 1, rgb8, rgb8_on_device, radiance, radiance_on_device, nullptr);
+}
+
+int ff_deinterleave_strips(FfState* s, const void* src_dev, void* dst_dev, int width, int height, int strip_rows, int num_parts, int elem_bytes)
+{
+    clear_error();
+    if (!s || !src_dev || !dst_dev) return fail(FF_ERR_INVALID_ARG, "ff_deinterleave_strips: null argument");
+    if (width <= 0 || height <= 0 || strip_rows <= 0 || num_parts <= 0 || elem_bytes <= 0) return fail(FF_ERR_INVALID_ARG, "ff_deinterleave_strips: bad geometry");
+    FF_HIP(hipSetDevice(s->device));
+    FF_HIP(launch_deinterleave(src_dev, dst_dev, width, height, strip_rows, num_parts, elem_bytes, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    return FF_OK;
+}
+
+int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, int trace_mode)
+{
+    clear_error();
+    if (!s || !rays || !out) return fail(FF_ERR_INVALID_ARG, "ff_intersect_rays: null argument");
+    if (n < 0) return fail(FF_ERR_INVALID_ARG, "ff_intersect_rays: negative count");
+    if (trace_mode != FF_TRACE_BRUTE_FORCE && trace_mode != FF_TRACE_BVH) return fail(FF_ERR_INVALID_ARG, "unknown trace_mode %d", trace_mode);
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_intersect_rays: no scene uploaded");
+    if (n == 0) return FF_OK;
+    FF_HIP(hipSetDevice(s->device));
+    FfRay* d_rays = nullptr;
+    FfIntersect* d_out = nullptr;
+    FF_HIP(hipMalloc((void**)&d_rays, (size_t)n * sizeof(FfRay)));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n * sizeof(FfIntersect));
+    if (e != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(FF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    RayBatchParams p;
+    p.rays = d_rays;
+    p.out = d_out;
+    p.n = n;
+    p.num_geoms = s->num_geoms;
+    p.geoms = s->d_geoms;
+    p.tris = s->d_tris;
+    p.nodes = s->d_nodes;
+    p.stack_depth = s->max_depth + 2;
+    p.lds_nodes = s->num_nodes < max_lds_nodes(p.stack_depth) ? s->num_nodes : max_lds_nodes(p.stack_depth);
+    e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * sizeof(FfIntersect), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(FF_ERR_HIP, "ff_intersect_rays failed: %s", hipGetErrorString(e));
+    return FF_OK;
+}
+
+// ---- OpenGL pixel-buffer interop ---------------------------------------------------------------------------------
+
+int ff_register_gl_pbo(FfState* s, unsigned int pbo, int width, int height)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_register_gl_pbo: state is null");
+    if (width <= 0 || height <= 0) return fail(FF_ERR_INVALID_ARG, "ff_register_gl_pbo: bad size");
+    (void)hipSetDevice(s->device);
+    if (s->pbo_resource) {
+        (void)hipGraphicsUnregisterResource(s->pbo_resource);
+        s->pbo_resource = nullptr;
+    }
+    // utilities.h:618: cudaGraphicsGLRegisterBuffer(&pboCudaResource, pbo, cudaGraphicsRegisterFlagsWriteDiscard)
+    hipGraphicsResource* res = nullptr;
+    hipError_t e = hipGraphicsGLRegisterBuffer(&res, (GLuint)pbo, hipGraphicsRegisterFlagsWriteDiscard);
+    if (e != hipSuccess || !res) {
+        (void)hipGetLastError();
+        return fail(FF_ERR_GL_UNAVAILABLE, "hipGraphicsGLRegisterBuffer(%u) failed: %s (is a GL context current on this thread?)", pbo, hipGetErrorString(e));
+    }
+    s->pbo_resource = res;
+    s->pbo_width = width;
+    s->pbo_height = height;
+    return FF_OK;
+}
+
+int ff_unregister_gl_pbo(FfState* s)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_unregister_gl_pbo: state is null");
+    if (!s->pbo_resource) return FF_OK;
+    (void)hipSetDevice(s->device);
+    hipError_t e = hipGraphicsUnregisterResource(s->pbo_resource); // utilities.h:516
+    s->pbo_resource = nullptr;
+    if (e != hipSuccess) return fail(FF_ERR_HIP, "hipGraphicsUnregisterResource failed: %s", hipGetErrorString(e));
+    return FF_OK;
+}
+
+int ff_render_to_pbo(FfState* s, const FfCamera* camera, const FfRenderParams* params)
+{
+    clear_error();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo: state is null");
+    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo: camera is null");
+    int st = check_params(params);
+    if (st != FF_OK) return st;
+    if (!s->pbo_resource) return fail(FF_ERR_GL_UNAVAILABLE, "ff_render_to_pbo: no pixel buffer registered");
+    if (params->width != s->pbo_width || params->height != s->pbo_height)
+        return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo: params are %dx%d but the registered buffer is %dx%d", params->width, params->height, s->pbo_width, s->pbo_height);
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_to_pbo: no scene uploaded");
+    FF_HIP(hipSetDevice(s->device));
+    // kernel.cu:335-344
+    void* dptr = nullptr;
+    size_t nbytes = 0;
+    FF_HIP(hipGraphicsMapResources(1, &s->pbo_resource, s->stream));                 // :338
+    hipError_t e = hipGraphicsResourceGetMappedPointer(&dptr, &nbytes, s->pbo_resource); // :339
+    if (e == hipSuccess && nbytes < (size_t)params->width * (size_t)params->height * 3) e = hipErrorInvalidValue;
+    if (e == hipSuccess) {
+        st = render_local(s, camera, params, params->height, 0, 1, params->height, (unsigned char*)dptr, nullptr); // :340-342
+    } else {
+        st = fail(FF_ERR_HIP, "mapping the pixel buffer failed: %s", hipGetErrorString(e));
+    }
+    hipError_t ue = hipGraphicsUnmapResources(1, &s->pbo_resource, s->stream);       // :344
+    if (st == FF_OK && ue != hipSuccess) st = fail(FF_ERR_HIP, "hipGraphicsUnmapResources failed: %s", hipGetErrorString(ue));
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------------------
+
+int ff_set_collect_stats(FfState* s, int on)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_set_collect_stats: state is null");
+    s->collect_stats = on != 0;
+    return FF_OK;
+}
+
+int ff_stats(FfState* s, FfStats* out)
+{
+    clear_error();
+    if (!s || !out) return fail(FF_ERR_INVALID_ARG, "ff_stats: null argument");
+    *out = s->stats;
+    return FF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,90 @@
+// ff_internal.h — declarations shared by the library's translation units (not part of the ABI).
+#pragma once
+
+#include <cstdarg>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/firefly/ff_api.h"
+
+namespace ff {
+
+// ---- error reporting (replaces the reference's print-and-exit macro, utilities.h:27-37) ----
+int fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+// ---- device-side scene records ---------------------------------------------------------------
+//
+// All records are built on the host by the scene compiler (ff_scene.cpp) and copied once per upload.
+
+// One 48-byte triangle record, stored in BVH-leaf order.  Only what intersectTriangle reads
+// (kernel.cu:39-41) plus the triangle's index in the caller's array (kernel.cu:152).
+struct TriRecord {
+    float v0[3];
+    int32_t orig_index; // index j in Geometry::m_triangles
+    float v1[3];
+    int32_t pad0;
+    float v2[3];
+    int32_t pad1;
+};
+static_assert(sizeof(TriRecord) == 48, "48-byte triangle record");
+
+// One 64-byte inner BVH node: both child boxes (object space, conservatively padded) and both child links.
+// link >= 0: index of an inner node (global node array).  link < 0: leaf, ~link = (first_tri << 3) | (count - 1),
+// first_tri indexing the global TriRecord array.  A mesh that fits one leaf has both links on that leaf.
+struct BvhNode {
+    float lmin[3];
+    int32_t left;
+    float lmax[3];
+    int32_t right;
+    float rmin[3];
+    int32_t pad0;
+    float rmax[3];
+    int32_t pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "64-byte BVH node");
+
+// Per-geometry record (wave-uniform reads in the kernel).  Matrices are stored as xyz columns.
+struct GeomRecord {
+    // m_inverseModelMatrix columns 0..3 (xyz).  The w slots of columns 0..2 hold (column3 * 0.0f).xyz, the signed zero
+    // glm adds when it transforms a direction (vec4 with w = 0, kernel.cu:138).
+    float inv_c0[4], inv_c1[4], inv_c2[4], inv_c3[4];
+    float mod_c0[4], mod_c1[4], mod_c2[4], mod_c3[4]; // m_modelMatrix columns (xyz)
+    // inverse(transpose(model)) columns 0..2 (kernel.cu:117); w slots hold (column3 * 0.0f).xyz as above.
+    float nrm_c0[4], nrm_c1[4], nrm_c2[4];
+    float plane_n[4];                                 // m_normal (utilities.h:229)
+    float albedo[4];                                  // BXDF::m_albedo
+    float emission[4];                                // BXDF::m_emissiveColor * m_intensity (utilities.h:102)
+    int32_t type;                                     // FfGeometryType
+    int32_t bxdf_type;                                // FfBXDFType
+    int32_t tri_first;                                // first TriRecord of this mesh
+    int32_t tri_count;
+    int32_t bvh_root;                                 // inner-node index of this mesh's root, -1 if none
+    int32_t pad[3];
+};
+static_assert(sizeof(GeomRecord) == 14 * 16 + 32, "GeomRecord layout");
+
+struct CompiledScene {
+    std::vector<GeomRecord> geoms;
+    std::vector<TriRecord> tris;   // leaf order
+    std::vector<BvhNode> nodes;    // all meshes, each mesh's nodes contiguous in breadth-first order
+    int max_depth = 0;             // deepest root-to-leaf path in inner nodes over all meshes
+    uint64_t total_tris = 0;
+};
+
+struct BvhBuildParams {
+    int max_leaf_tris = 4; // <= 8
+    int max_depth = 30;    // hard bound on inner-node depth (the traversal stack is sized from the built depth)
+    int bins = 16;
+};
+
+// Build the object-space BVH of one mesh.  Appends inner nodes to `nodes` (breadth-first, root first) and the mesh's
+// triangles, in leaf order, to `tris`.  Returns the root inner-node index (into `nodes`) and the tree depth.
+int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams& params, std::vector<BvhNode>& nodes,
+                   std::vector<TriRecord>& tris, int* out_depth);
+
+// Flatten host geometries into device records.  Returns an FfStatus.
+int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out);
+
+} // namespace ff

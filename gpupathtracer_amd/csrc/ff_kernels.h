@@ -1,0 +1,70 @@
+// ff_kernels.h — host-visible launch interface of the gfx950 trace kernels (ff_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ff_internal.h"
+
+namespace ff {
+
+constexpr int kBlockThreads = 512;        // 8 waves per workgroup, one workgroup per CU shares one LDS copy of the BVH top
+constexpr int kLdsBudgetBytes = 160 * 1024;
+constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
+
+// Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).
+struct KParams {
+    // camera: columns of invView*invProj (kernel.cu:203), position, far plane, screen size as floats (kernel.cu:200-201)
+    float cam_c0[4], cam_c1[4], cam_c2[4], cam_c3[4];
+    float cam_pos[3];
+    float far_clip;
+    float screen_w, screen_h;
+    int width, height; // full image size in pixels (row stride = width)
+    int xlim, ylim;    // pixels with x >= xlim or y >= ylim are not traced (FF_GRID_REFERENCE_FLOOR)
+    // work decomposition: local rows of this part, in strips
+    int strip_rows, part, num_parts, local_rows;
+    unsigned total_items; // number of work items (64 per 8x8 pixel tile of the local image)
+    int tiles_per_row;
+    // integrator
+    int bounces, spp_begin, spp_end, spp_total;
+    unsigned key;       // Philox key (seed folded to 32 bits)
+    int shade_mode;
+    int first_chunk, last_chunk;
+    // scene
+    int num_geoms;
+    const GeomRecord* geoms;
+    const TriRecord* tris;
+    const BvhNode* nodes;
+    int lds_nodes;   // nodes [0, lds_nodes) are staged in LDS
+    int stack_depth; // entries per lane in the LDS traversal stack
+    // outputs (local image: local_rows x width)
+    float* accum;            // float4 per local pixel: running radiance sum across spp chunks
+    unsigned char* rgb8;     // 3 bytes per local pixel, or null
+    float* radiance;         // 3 floats per local pixel, or null
+    unsigned* queue;         // work-item counter (zeroed before each launch)
+    unsigned long long* counters; // [0] rays [1] inner-node visits [2] triangle tests [3] plane tests
+};
+
+struct RayBatchParams {
+    const FfRay* rays;
+    FfIntersect* out;
+    int n;
+    int num_geoms;
+    const GeomRecord* geoms;
+    const TriRecord* tris;
+    const BvhNode* nodes;
+    int lds_nodes;
+    int stack_depth;
+};
+
+// LDS bytes the BVH kernels need for (lds_nodes, stack_depth).
+size_t bvh_lds_bytes(int lds_nodes, int stack_depth);
+// Largest node count that fits LDS next to a stack of `stack_depth` entries per lane.
+int max_lds_nodes(int stack_depth);
+
+hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, hipStream_t stream);
+hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream);
+hipError_t launch_deinterleave(const void* src, void* dst, int width, int height, int strip_rows, int num_parts, int elem_bytes,
+                               hipStream_t stream);
+hipError_t prepare_kernels(); // one-time function attributes (dynamic LDS limit)
+
+} // namespace ff

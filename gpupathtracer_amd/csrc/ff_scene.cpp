@@ -1,0 +1,435 @@
+// ff_scene.cpp — the scene compiler: host Geometry[] (array of structs with owning pointers, utilities.h:219-233)
+// -> flat device records (GeomRecord[], 48-byte TriRecord[] in leaf order, 64-byte BvhNode[] per mesh).
+//
+// This replaces the reference's deep-copy upload (kernel.cu:268-298), which ships the 208-byte Geometry and the
+// 96-byte AoS Triangle verbatim.  Triangles stay in OBJECT space and keep their values bit-for-bit, because the
+// reference intersects in object space (kernel.cu:138) and ranks hits by world distance (kernel.cu:113-121); the
+// BVH therefore is one object-space tree per mesh and only prunes work, it never changes a computed hit.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "ff_internal.h"
+#include "ff_math.h"
+
+namespace ff {
+
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset()
+    {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::numeric_limits<float>::infinity();
+            mx[k] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const float* p)
+    {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], p[k]);
+            mx[k] = std::max(mx[k], p[k]);
+        }
+    }
+    void grow(const Box& b)
+    {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], b.mn[k]);
+            mx[k] = std::max(mx[k], b.mx[k]);
+        }
+    }
+    float half_area() const
+    {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct BuildNode {
+    Box box;
+    int left = -1, right = -1; // children (BuildNode indices), -1 for leaves
+    int start = 0, count = 0;  // range in the permutation array
+    int depth = 0;
+};
+
+struct Builder {
+    const FfTriangle* tris;
+    const BvhBuildParams& P;
+    std::vector<Box> tbox;
+    std::vector<float> cent; // 3 per triangle
+    std::vector<int> perm;
+    std::vector<BuildNode> bn;
+
+    Builder(const FfTriangle* t, int n, const BvhBuildParams& p) : tris(t), P(p), tbox(n), cent(3 * (size_t)n), perm(n)
+    {
+        for (int i = 0; i < n; ++i) {
+            Box b;
+            b.reset();
+            b.grow(&t[i].m_v0.x);
+            b.grow(&t[i].m_v1.x);
+            b.grow(&t[i].m_v2.x);
+            tbox[i] = b;
+            for (int k = 0; k < 3; ++k) cent[3 * (size_t)i + k] = 0.5f * (b.mn[k] + b.mx[k]);
+        }
+        std::iota(perm.begin(), perm.end(), 0);
+    }
+
+    Box range_box(int start, int count) const
+    {
+        Box b;
+        b.reset();
+        for (int i = 0; i < count; ++i) b.grow(tbox[perm[start + i]]);
+        return b;
+    }
+
+    // Returns the split position (number of triangles going left) after partitioning perm[start, start+count), or 0 for "make a leaf".
+    int split(int start, int count, const Box& box, int depth)
+    {
+        const int remaining = P.max_depth - depth;            // inner levels still allowed below this node
+        const long cap_child = remaining >= 1 ? (long)P.max_leaf_tris << std::min(remaining - 1, 24) : 0;
+        const bool must_split = count > P.max_leaf_tris;
+        if (!must_split && count <= 1) return 0;
+
+        Box cb;
+        cb.reset();
+        for (int i = 0; i < count; ++i) cb.grow(&cent[3 * (size_t)perm[start + i]]);
+
+        const int NB = P.bins;
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_bin = -1;
+        std::vector<Box> bbox(NB), rbox(NB);
+        std::vector<int> bcnt(NB), lcnt(NB);
+        for (int ax = 0; ax < 3; ++ax) {
+            const float lo = cb.mn[ax], ext = cb.mx[ax] - cb.mn[ax];
+            if (!(ext > 0.f)) continue;
+            const float sc = (float)NB / ext;
+            for (int b = 0; b < NB; ++b) { bbox[b].reset(); bcnt[b] = 0; }
+            for (int i = 0; i < count; ++i) {
+                const int t = perm[start + i];
+                int b = (int)((cent[3 * (size_t)t + ax] - lo) * sc);
+                b = std::max(0, std::min(NB - 1, b));
+                bbox[b].grow(tbox[t]);
+                ++bcnt[b];
+            }
+            Box acc;
+            acc.reset();
+            for (int b = NB - 1; b >= 0; --b) { acc.grow(bbox[b]); rbox[b] = acc; }
+            acc.reset();
+            int nl = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                acc.grow(bbox[b]);
+                nl += bcnt[b];
+                const int nr = count - nl;
+                if (nl == 0 || nr == 0) continue;
+                const float cost = acc.half_area() * (float)nl + rbox[b + 1].half_area() * (float)nr;
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+            }
+        }
+
+        int nleft = 0;
+        if (best_axis >= 0) {
+            const float parent_area = box.half_area();
+            const float c_trav = 1.2f, c_tri = 1.0f;
+            const float split_cost = c_trav + (parent_area > 0.f ? best_cost / parent_area : (float)count) * c_tri;
+            if (!must_split && split_cost >= (float)count * c_tri) return 0;
+            const float lo = cb.mn[best_axis], sc = (float)NB / (cb.mx[best_axis] - cb.mn[best_axis]);
+            auto mid = std::partition(perm.begin() + start, perm.begin() + start + count, [&](int t) {
+                int b = (int)((cent[3 * (size_t)t + best_axis] - lo) * sc);
+                b = std::max(0, std::min(NB - 1, b));
+                return b <= best_bin;
+            });
+            nleft = (int)(mid - (perm.begin() + start));
+        } else if (!must_split) {
+            return 0;
+        }
+        // Depth guard / degenerate SAH: fall back to an object-median split on the widest centroid axis.
+        const bool unbalanced = nleft == 0 || nleft == count || (long)std::max(nleft, count - nleft) > cap_child;
+        if (unbalanced) {
+            int ax = 0;
+            float e = -1.f;
+            for (int k = 0; k < 3; ++k) {
+                const float ek = cb.mx[k] - cb.mn[k];
+                if (ek > e) { e = ek; ax = k; }
+            }
+            nleft = count / 2;
+            std::nth_element(perm.begin() + start, perm.begin() + start + nleft, perm.begin() + start + count, [&](int a, int b) {
+                const float ca = cent[3 * (size_t)a + ax], cb2 = cent[3 * (size_t)b + ax];
+                return ca < cb2 || (ca == cb2 && a < b);
+            });
+        }
+        return nleft;
+    }
+
+    void build()
+    {
+        BuildNode root;
+        root.start = 0;
+        root.count = (int)perm.size();
+        root.box = range_box(0, root.count);
+        root.depth = 0;
+        bn.push_back(root);
+        std::vector<int> todo{ 0 };
+        while (!todo.empty()) {
+            const int id = todo.back();
+            todo.pop_back();
+            const int start = bn[id].start, count = bn[id].count, depth = bn[id].depth;
+            const Box box = bn[id].box;
+            const int nleft = split(start, count, box, depth);
+            if (nleft <= 0) continue; // leaf
+            BuildNode l, r;
+            l.start = start; l.count = nleft; l.depth = depth + 1; l.box = range_box(l.start, l.count);
+            r.start = start + nleft; r.count = count - nleft; r.depth = depth + 1; r.box = range_box(r.start, r.count);
+            const int li = (int)bn.size();
+            bn.push_back(l);
+            const int ri = (int)bn.size();
+            bn.push_back(r);
+            bn[id].left = li;
+            bn[id].right = ri;
+            todo.push_back(li);
+            todo.push_back(ri);
+        }
+    }
+};
+
+} // namespace
+
+int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams& params, std::vector<BvhNode>& nodes,
+                   std::vector<TriRecord>& tris, int* out_depth)
+{
+    if (count <= 0) {
+        if (out_depth) *out_depth = 0;
+        return -1;
+    }
+    Builder B(triangles, count, params);
+    B.build();
+
+    // Conservative padding: the triangle test accepts hits whose geometric miss distance is a few ulps of the
+    // coordinates involved; boxes are grown by 1e-4 of the mesh's largest |coordinate| (>> those ulps) so that every
+    // triangle hit the brute-force loop would report lies inside all boxes on its root path.
+    float big = 0.f;
+    for (int k = 0; k < 3; ++k) big = std::max(big, std::max(std::fabs(B.bn[0].box.mn[k]), std::fabs(B.bn[0].box.mx[k])));
+    const float pad = 1e-4f * std::max(big, 1e-3f);
+
+    const int tri_base = (int)tris.size();
+    for (int i = 0; i < count; ++i) {
+        const FfTriangle& t = triangles[B.perm[i]];
+        TriRecord r;
+        std::memset(&r, 0, sizeof r);
+        std::memcpy(r.v0, &t.m_v0, 12);
+        std::memcpy(r.v1, &t.m_v1, 12);
+        std::memcpy(r.v2, &t.m_v2, 12);
+        r.orig_index = B.perm[i];
+        tris.push_back(r);
+    }
+
+    // Breadth-first numbering of inner nodes; a mesh that fits one leaf still gets an inner root with an empty right child.
+    const int node_base = (int)nodes.size();
+    auto leaf_link = [&](const BuildNode& n) { return ~(((tri_base + n.start) << 3) | (n.count - 1)); };
+    auto put_box = [&](const BuildNode& n, float* mn, float* mx) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = n.box.mn[k] - pad;
+            mx[k] = n.box.mx[k] + pad;
+        }
+    };
+    int depth = 1;
+    if (B.bn[0].left < 0) {
+        // Single-leaf mesh: both links point at the same leaf (testing a triangle twice cannot change the closest hit).
+        BvhNode nd;
+        std::memset(&nd, 0, sizeof nd);
+        put_box(B.bn[0], nd.lmin, nd.lmax);
+        put_box(B.bn[0], nd.rmin, nd.rmax);
+        nd.left = leaf_link(B.bn[0]);
+        nd.right = nd.left;
+        nodes.push_back(nd);
+    } else {
+        std::vector<int> order; // build-node ids of inner nodes in BFS order
+        std::vector<int> bfs_index(B.bn.size(), -1);
+        order.push_back(0);
+        bfs_index[0] = 0;
+        for (size_t q = 0; q < order.size(); ++q) {
+            const BuildNode& n = B.bn[order[q]];
+            for (int child : { n.left, n.right }) {
+                if (B.bn[child].left >= 0) {
+                    bfs_index[child] = (int)order.size();
+                    order.push_back(child);
+                }
+            }
+        }
+        for (size_t q = 0; q < order.size(); ++q) {
+            const BuildNode& n = B.bn[order[q]];
+            const BuildNode& l = B.bn[n.left];
+            const BuildNode& r = B.bn[n.right];
+            BvhNode nd;
+            std::memset(&nd, 0, sizeof nd);
+            put_box(l, nd.lmin, nd.lmax);
+            put_box(r, nd.rmin, nd.rmax);
+            nd.left = l.left >= 0 ? node_base + bfs_index[n.left] : leaf_link(l);
+            nd.right = r.left >= 0 ? node_base + bfs_index[n.right] : leaf_link(r);
+            nodes.push_back(nd);
+            depth = std::max(depth, n.depth + 1);
+        }
+    }
+    if (out_depth) *out_depth = depth;
+    return node_base;
+}
+
+int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out)
+{
+    using namespace ffm;
+    out = CompiledScene();
+    if (!geoms || n <= 0) return fail(FF_ERR_INVALID_ARG, "ff_upload_scene: no geometries");
+    if (params.max_leaf_tris < 1 || params.max_leaf_tris > 8) return fail(FF_ERR_INVALID_ARG, "max_leaf_tris must be 1..8");
+    out.geoms.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const FfGeometry& g = geoms[i];
+        GeomRecord& r = out.geoms[i];
+        std::memset(&r, 0, sizeof r);
+        if (g.m_geometryType != FF_GEOM_PLANE && g.m_geometryType != FF_GEOM_TRIANGLEMESH)
+            return fail(FF_ERR_UNSUPPORTED, "geometry %d: type %d is not implemented (the reference only prints, kernel.cu:166-173)", i,
+                        g.m_geometryType);
+        if (!g.m_bxdf) return fail(FF_ERR_INVALID_ARG, "geometry %d: m_bxdf is null (the reference copies it unconditionally, kernel.cu:282)", i);
+        const M4 inv = load(g.m_inverseModelMatrix.m), mod = load(g.m_modelMatrix.m);
+        // The kernel drops the w row of the object-space transform (kernel.cu:138 normalises a vec4 whose w is 0 for
+        // affine matrices); refuse matrices for which that is not exact.
+        if (inv.c[0].w != 0.f || inv.c[1].w != 0.f || inv.c[2].w != 0.f || mod.c[0].w != 0.f || mod.c[1].w != 0.f || mod.c[2].w != 0.f)
+            return fail(FF_ERR_UNSUPPORTED, "geometry %d: model matrix is not affine", i);
+        const M4 nrm = inverse(transpose(mod)); // kernel.cu:117, hoisted out of the per-hit path
+        std::memcpy(r.inv_c0, &inv.c[0], 16); std::memcpy(r.inv_c1, &inv.c[1], 16);
+        std::memcpy(r.inv_c2, &inv.c[2], 16); std::memcpy(r.inv_c3, &inv.c[3], 16);
+        std::memcpy(r.mod_c0, &mod.c[0], 16); std::memcpy(r.mod_c1, &mod.c[1], 16);
+        std::memcpy(r.mod_c2, &mod.c[2], 16); std::memcpy(r.mod_c3, &mod.c[3], 16);
+        std::memcpy(r.nrm_c0, &nrm.c[0], 16); std::memcpy(r.nrm_c1, &nrm.c[1], 16); std::memcpy(r.nrm_c2, &nrm.c[2], 16);
+        // glm's mat4*vec4 adds column3*w even when w == 0; keep that signed zero so directions/normals match bit-for-bit.
+        r.inv_c0[3] = inv.c[3].x * 0.0f; r.inv_c1[3] = inv.c[3].y * 0.0f; r.inv_c2[3] = inv.c[3].z * 0.0f;
+        r.nrm_c0[3] = nrm.c[3].x * 0.0f; r.nrm_c1[3] = nrm.c[3].y * 0.0f; r.nrm_c2[3] = nrm.c[3].z * 0.0f;
+        r.plane_n[0] = g.m_normal.x; r.plane_n[1] = g.m_normal.y; r.plane_n[2] = g.m_normal.z;
+        const FfBXDF& b = *g.m_bxdf;
+        r.albedo[0] = b.m_albedo.x; r.albedo[1] = b.m_albedo.y; r.albedo[2] = b.m_albedo.z;
+        r.emission[0] = b.m_emissiveColor.x * b.m_intensity; // utilities.h:102
+        r.emission[1] = b.m_emissiveColor.y * b.m_intensity;
+        r.emission[2] = b.m_emissiveColor.z * b.m_intensity;
+        r.type = g.m_geometryType;
+        r.bxdf_type = b.m_type;
+        r.bvh_root = -1;
+        if (g.m_geometryType == FF_GEOM_TRIANGLEMESH) {
+            const int cnt = g.m_triangles ? g.m_numberOfTriangles : 0;
+            if (cnt < 0) return fail(FF_ERR_INVALID_ARG, "geometry %d: negative triangle count", i);
+            if ((uint64_t)out.tris.size() + (uint64_t)cnt >= (1ull << 28))
+                return fail(FF_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles");
+            r.tri_first = (int)out.tris.size();
+            r.tri_count = cnt;
+            int depth = 0;
+            r.bvh_root = build_mesh_bvh(g.m_triangles, cnt, params, out.nodes, out.tris, &depth);
+            out.max_depth = std::max(out.max_depth, depth);
+            out.total_tris += (uint64_t)cnt;
+        }
+    }
+    return FF_OK;
+}
+
+} // namespace ff
+
+// ---- host-only dry run + structural self-check -------------------------------------------------------------------
+
+namespace ff {
+size_t bvh_lds_bytes(int lds_nodes, int stack_depth);
+int max_lds_nodes(int stack_depth);
+
+namespace {
+
+// Walks every mesh BVH: each triangle must be referenced by exactly one leaf, and every child box must enclose the
+// triangles (and boxes) below it.
+bool check_bvh(const CompiledScene& cs, int* out_max_leaf)
+{
+    std::vector<int> seen(cs.tris.size(), 0);
+    int max_leaf = 0;
+    bool ok = true;
+    struct Item {
+        int link;
+        float mn[3], mx[3];
+    };
+    for (const GeomRecord& g : cs.geoms) {
+        if (g.type != FF_GEOM_TRIANGLEMESH || g.bvh_root < 0) continue;
+        std::vector<Item> todo;
+        Item root;
+        root.link = g.bvh_root;
+        for (int k = 0; k < 3; ++k) { root.mn[k] = -std::numeric_limits<float>::infinity(); root.mx[k] = std::numeric_limits<float>::infinity(); }
+        todo.push_back(root);
+        const bool single_leaf = cs.nodes[g.bvh_root].left < 0 && cs.nodes[g.bvh_root].left == cs.nodes[g.bvh_root].right;
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            if (it.link >= 0) {
+                if (it.link >= (int)cs.nodes.size()) return false;
+                const BvhNode& n = cs.nodes[it.link];
+                Item l, r;
+                l.link = n.left; r.link = n.right;
+                for (int k = 0; k < 3; ++k) {
+                    l.mn[k] = n.lmin[k]; l.mx[k] = n.lmax[k]; r.mn[k] = n.rmin[k]; r.mx[k] = n.rmax[k];
+                    if (n.lmin[k] < it.mn[k] - 1e-3f || n.lmax[k] > it.mx[k] + 1e-3f) ok = false;
+                    if (n.rmin[k] < it.mn[k] - 1e-3f || n.rmax[k] > it.mx[k] + 1e-3f) ok = false;
+                }
+                todo.push_back(l);
+                if (!(single_leaf && it.link == g.bvh_root)) todo.push_back(r);
+            } else {
+                const int ref = ~it.link, first = ref >> 3, count = (ref & 7) + 1;
+                max_leaf = std::max(max_leaf, count);
+                if (first < g.tri_first || first + count > g.tri_first + g.tri_count) return false;
+                for (int i = first; i < first + count; ++i) {
+                    ++seen[i];
+                    const TriRecord& t = cs.tris[i];
+                    for (const float* v : { t.v0, t.v1, t.v2 })
+                        for (int k = 0; k < 3; ++k)
+                            if (!(v[k] >= it.mn[k] && v[k] <= it.mx[k])) ok = false;
+                }
+            }
+        }
+        // every original index must appear exactly once
+        std::vector<int> orig(g.tri_count, 0);
+        for (int i = g.tri_first; i < g.tri_first + g.tri_count; ++i) {
+            const int o = cs.tris[i].orig_index;
+            if (o < 0 || o >= g.tri_count) return false;
+            ++orig[o];
+        }
+        for (int c : orig) if (c != 1) ok = false;
+    }
+    for (int c : seen) if (c != 1) ok = false;
+    if (out_max_leaf) *out_max_leaf = max_leaf;
+    return ok;
+}
+
+} // namespace
+} // namespace ff
+
+extern "C" int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneInfo* out)
+{
+    using namespace ff;
+    clear_error();
+    if (!out) return fail(FF_ERR_INVALID_ARG, "ff_scene_info: out_info is null");
+    std::memset(out, 0, sizeof *out);
+    CompiledScene cs;
+    BvhBuildParams bp;
+    const int st = compile_scene(host_geometries, n, bp, cs);
+    if (st != FF_OK) return st;
+    out->num_geometries = (int)cs.geoms.size();
+    for (const GeomRecord& g : cs.geoms) {
+        if (g.type == FF_GEOM_TRIANGLEMESH) ++out->num_meshes;
+        else ++out->num_planes;
+    }
+    out->bvh_nodes = (int)cs.nodes.size();
+    out->bvh_max_depth = cs.max_depth;
+    out->num_triangles = cs.tris.size();
+    const int stack_depth = cs.max_depth + 2;
+    out->lds_nodes = std::min((int)cs.nodes.size(), std::max(0, max_lds_nodes(stack_depth)));
+    out->lds_bytes = (int)bvh_lds_bytes(out->lds_nodes, stack_depth);
+    out->device_bytes = cs.geoms.size() * sizeof(GeomRecord) + cs.tris.size() * sizeof(TriRecord) + cs.nodes.size() * sizeof(BvhNode);
+    int max_leaf = 0;
+    out->valid = check_bvh(cs, &max_leaf) ? 1 : 0;
+    out->bvh_max_leaf = max_leaf;
+    return FF_OK;
+}

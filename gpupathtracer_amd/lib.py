@@ -1,0 +1,213 @@
+"""ctypes binding of the C ABI in include/firefly/ff_api.h (libfirefly_hip.so, built in-tree by
+``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C gpupathtracer_amd/csrc``).
+
+There is no CPU fallback: if the HIP library is missing, importing this module's ``load()`` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfirefly_hip.so")
+
+# every exported symbol declared in include/firefly/ff_api.h
+EXPORTS = [
+    "ff_create", "ff_destroy", "ff_last_error", "ff_version", "ff_set_stream",
+    "ff_geometry_init", "ff_bxdf_init", "ff_camera_init_default", "ff_camera_update_basis", "ff_camera_ray_matrix",
+    "ff_upload_scene", "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
+    "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
+    "ff_set_collect_stats", "ff_stats", "ff_load_obj", "ff_free_triangles",
+]
+
+_lib = None
+
+
+class FireflyError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"firefly status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def load():
+    """Load libfirefly_hip.so (once) and declare prototypes. Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built (run __graft_entry__.build()); "
+            "there is no CPU fallback for the trace path")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    P = C.POINTER
+    lib.ff_create.argtypes = [P(vp), i32]
+    lib.ff_destroy.argtypes = [vp]
+    lib.ff_last_error.restype = C.c_char_p
+    lib.ff_version.restype = i32
+    lib.ff_set_stream.argtypes = [vp, vp]
+    lib.ff_geometry_init.argtypes = [P(T.FfGeometry), i32, T.FfVec3, T.FfVec3, T.FfVec3, P(T.FfTriangle), i32, f32]
+    lib.ff_geometry_init.restype = None
+    lib.ff_bxdf_init.argtypes = [P(T.FfBXDF)]
+    lib.ff_bxdf_init.restype = None
+    lib.ff_camera_init_default.argtypes = [P(T.FfCamera), i32, i32]
+    lib.ff_camera_init_default.restype = None
+    lib.ff_camera_update_basis.argtypes = [P(T.FfCamera)]
+    lib.ff_camera_update_basis.restype = None
+    lib.ff_camera_ray_matrix.argtypes = [P(T.FfCamera), P(T.FfMat4)]
+    lib.ff_camera_ray_matrix.restype = None
+    lib.ff_upload_scene.argtypes = [vp, P(T.FfGeometry), i32]
+    lib.ff_scene_info.argtypes = [P(T.FfGeometry), i32, P(T.FfSceneInfo)]
+    lib.ff_render.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), vp, i32, vp, i32]
+    lib.ff_render_strips.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, i32, i32, vp, i32, vp, i32, P(i32)]
+    lib.ff_strips_local_rows.argtypes = [i32, i32, i32, i32]
+    lib.ff_deinterleave_strips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
+    lib.ff_intersect_rays.argtypes = [vp, P(T.FfRay), i32, P(T.FfIntersect), i32]
+    lib.ff_register_gl_pbo.argtypes = [vp, C.c_uint, i32, i32]
+    lib.ff_unregister_gl_pbo.argtypes = [vp]
+    lib.ff_render_to_pbo.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams)]
+    lib.ff_set_collect_stats.argtypes = [vp, i32]
+    lib.ff_stats.argtypes = [vp, P(T.FfStats)]
+    lib.ff_load_obj.argtypes = [C.c_char_p, P(P(T.FfTriangle)), P(i32)]
+    lib.ff_free_triangles.argtypes = [P(T.FfTriangle)]
+    lib.ff_free_triangles.restype = None
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != T.FF_OK:
+        raise FireflyError(status, load().ff_last_error().decode("utf-8", "replace"))
+
+
+def load_obj(path):
+    """LoadMesh (utilities.h:781-840) -> float32 [n, 24] triangles."""
+    lib = load()
+    ptr = C.POINTER(T.FfTriangle)()
+    n = C.c_int(0)
+    check(lib.ff_load_obj(os.fsencode(path), C.byref(ptr), C.byref(n)))
+    try:
+        return T.triangles_to_array(ptr, n.value)
+    finally:
+        lib.ff_free_triangles(ptr)
+
+
+def scene_info(scene):
+    """Host-only dry run of the scene compiler (sizes, BVH shape, structural self-check)."""
+    info = T.FfSceneInfo()
+    check(load().ff_scene_info(scene.geometries, len(scene.geometries), C.byref(info)))
+    return info
+
+
+def render_params(width, height, bounces=1, spp=1, seed=1234, trace_mode=T.TRACE_BVH, shade_mode=T.SHADE_DIFFUSE_PATH,
+                  grid_mode=T.GRID_FULL, spp_per_launch=0):
+    return T.FfRenderParams(width, height, bounces, spp, seed, trace_mode, shade_mode, grid_mode, spp_per_launch)
+
+
+class Tracer:
+    """Owner of one FfState (one HIP device). Mirrors the call sequence of the reference's main():
+    upload once (kernel.cu:268-298), then render per frame (kernel.cu:335-344)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load()
+        self._state = C.c_void_p()
+        check(self._lib.ff_create(C.byref(self._state), device_id))
+        self._scene_keepalive = None
+
+    def close(self):
+        if self._state:
+            self._lib.ff_destroy(self._state)
+            self._state = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_ptr):
+        check(self._lib.ff_set_stream(self._state, C.c_void_p(hip_stream_ptr)))
+
+    def upload_scene(self, scene):
+        """scene: gpupathtracer_amd.scenes.Scene"""
+        check(self._lib.ff_upload_scene(self._state, scene.geometries, len(scene.geometries)))
+
+    def set_collect_stats(self, on):
+        check(self._lib.ff_set_collect_stats(self._state, 1 if on else 0))
+
+    def stats(self):
+        st = T.FfStats()
+        check(self._lib.ff_stats(self._state, C.byref(st)))
+        return st
+
+    def render(self, camera, params, want_rgb8=True, want_radiance=True):
+        """Headless frame to host numpy arrays: (rgb8 [H,W,3] uint8, radiance [H,W,3] float32)."""
+        h, w = params.height, params.width
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if want_rgb8 else None
+        rad = np.zeros((h, w, 3), dtype=np.float32) if want_radiance else None
+        check(self._lib.ff_render(self._state, C.byref(camera), C.byref(params),
+                                  rgb8.ctypes.data if want_rgb8 else None, 0,
+                                  rad.ctypes.data if want_radiance else None, 0))
+        return rgb8, rad
+
+    def render_device(self, camera, params, rgb8_ptr=None, radiance_ptr=None):
+        """Headless frame into caller-owned DEVICE buffers (raw pointers, e.g. torch tensor.data_ptr())."""
+        check(self._lib.ff_render(self._state, C.byref(camera), C.byref(params),
+                                  C.c_void_p(rgb8_ptr) if rgb8_ptr else None, 1,
+                                  C.c_void_p(radiance_ptr) if radiance_ptr else None, 1))
+
+    def strips_local_rows(self, height, strip_rows, part, num_parts):
+        return self._lib.ff_strips_local_rows(height, strip_rows, part, num_parts)
+
+    def render_strips(self, camera, params, strip_rows, part, num_parts, want_rgb8=True, want_radiance=True):
+        rows = self._lib.ff_strips_local_rows(params.height, strip_rows, part, num_parts)
+        w = params.width
+        rgb8 = np.zeros((rows, w, 3), dtype=np.uint8) if want_rgb8 else None
+        rad = np.zeros((rows, w, 3), dtype=np.float32) if want_radiance else None
+        n = C.c_int(0)
+        check(self._lib.ff_render_strips(self._state, C.byref(camera), C.byref(params), strip_rows, part, num_parts,
+                                         rgb8.ctypes.data if want_rgb8 and rows else None, 0,
+                                         rad.ctypes.data if want_radiance and rows else None, 0, C.byref(n)))
+        assert n.value == rows
+        return rgb8, rad
+
+    def render_strips_device(self, camera, params, strip_rows, part, num_parts, rgb8_ptr=None, radiance_ptr=None):
+        n = C.c_int(0)
+        check(self._lib.ff_render_strips(self._state, C.byref(camera), C.byref(params), strip_rows, part, num_parts,
+                                         C.c_void_p(rgb8_ptr) if rgb8_ptr else None, 1,
+                                         C.c_void_p(radiance_ptr) if radiance_ptr else None, 1, C.byref(n)))
+        return n.value
+
+    def deinterleave_strips(self, src_ptr, dst_ptr, width, height, strip_rows, num_parts, elem_bytes):
+        check(self._lib.ff_deinterleave_strips(self._state, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), width, height,
+                                               strip_rows, num_parts, elem_bytes))
+
+    def intersect_rays(self, origins, directions, trace_mode=T.TRACE_BVH):
+        """intersectRays (kernel.cu:127-176) for arrays of world-space rays -> structured result arrays."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        rays = np.concatenate([o, d], axis=1).astype(np.float32)
+        rbuf = (T.FfRay * n)()
+        C.memmove(rbuf, rays.ctypes.data, rays.nbytes)
+        out = (T.FfIntersect * n)()
+        check(self._lib.ff_intersect_rays(self._state, rbuf, n, out, trace_mode))
+        return intersect_array(out, n)
+
+
+INTERSECT_DTYPE = np.dtype([("point", np.float32, 3), ("normal", np.float32, 3), ("t", np.float32), ("hit", np.uint8),
+                            ("_pad", np.uint8, 3), ("geom", np.int32), ("tri", np.int32)])
+assert INTERSECT_DTYPE.itemsize == 40
+
+
+def intersect_array(buf, n):
+    return np.frombuffer(bytes(buf), dtype=INTERSECT_DTYPE, count=n).copy()

@@ -1,0 +1,162 @@
+/*
+ * firefly/ff_api.h — C ABI of the MI355X path-tracing core (libfirefly_hip.so).
+ *
+ * The reference has no library seam: host and device code share one translation unit
+ * (PathTracer/FireflyEngine/kernel.cu).  This ABI is cut exactly at the two places where the
+ * reference's main() talks to the GPU:
+ *
+ *   scene upload   kernel.cu:268-298   -> ff_upload_scene
+ *   per-frame      kernel.cu:335-344   -> ff_render_to_pbo (GL viewer) / ff_render (headless twin)
+ *   PBO register   utilities.h:605-618 -> ff_register_gl_pbo,  utilities.h:516 -> ff_unregister_gl_pbo
+ *   kernel         kernel.cu:218-221   -> the trace kernels behind ff_render*
+ *
+ * Conventions: plain pointers and sizes only; every function returns an FfStatus (0 = ok) and never
+ * calls exit() (the reference's cudaCheckErrors macro does, utilities.h:27-37); the message for the
+ * last failure on the calling thread is available from ff_last_error().  All ff_render* calls are
+ * synchronous on return, which is the implicit contract the viewer relies on before glTexSubImage2D
+ * (kernel.cu:344-351).  The caller owns the host scene and all GL objects; the library owns all
+ * device memory it allocates.
+ */
+#ifndef FIREFLY_FF_API_H
+#define FIREFLY_FF_API_H
+
+#include "ff_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define FF_API __declspec(dllexport)
+#else
+#define FF_API __attribute__((visibility("default")))
+#endif
+
+typedef enum FfStatus {
+    FF_OK                 = 0,
+    FF_ERR_INVALID_ARG    = 1,
+    FF_ERR_NO_DEVICE      = 2,  /* no HIP device / HIP runtime failure at create */
+    FF_ERR_HIP            = 3,  /* a HIP call failed; see ff_last_error() */
+    FF_ERR_NO_SCENE       = 4,  /* render called before ff_upload_scene */
+    FF_ERR_UNSUPPORTED    = 5,  /* e.g. SPHERE geometry (kernel.cu:166-169 only printf's) */
+    FF_ERR_GL_UNAVAILABLE = 6,  /* HIP-GL interop not usable (headless box) */
+    FF_ERR_IO             = 7,  /* file could not be read / parsed */
+    FF_ERR_OOM            = 8
+} FfStatus;
+
+typedef struct FfState FfState; /* opaque; replaces PathTracerState (kernel.h:12-20) */
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+
+/* Create a tracer bound to HIP device `device_id`. */
+FF_API int ff_create(FfState** out_state, int device_id);
+FF_API int ff_destroy(FfState* state);
+
+/* Message of the last failure on this thread ("" if none). Never NULL. */
+FF_API const char* ff_last_error(void);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+FF_API int ff_version(void);
+
+/* Launch stream for all subsequent work of this state (a hipStream_t; NULL = default stream,
+ * which is what the reference uses, kernel.cu:342). */
+FF_API int ff_set_stream(FfState* state, void* hip_stream);
+
+/* ---- host-side helpers restating the reference's host code (bit-exact glm operation order) ---- */
+
+/* Geometry::Geometry(type, position, rotation, scale, triangles, radius)  utilities.h:176-213.
+ * Builds m_modelMatrix = T*Rx*Ry*Rz*S and its inverse.  `triangles` is borrowed, not copied. */
+FF_API void ff_geometry_init(FfGeometry* g, int geometry_type, FfVec3 position, FfVec3 rotation_deg,
+                             FfVec3 scale, FfTriangle* triangles, int number_of_triangles, float radius);
+
+/* BXDF default member initialisers utilities.h:81-88. */
+FF_API void ff_bxdf_init(FfBXDF* b);
+
+/* Camera default member initialisers utilities.h:287-291 plus the literals of kernel.cu:312-322
+ * (position (0,0,15), worldUp (0,1,0), fov 70, near .1, far 1000, yaw -90, pitch 0) for a W x H image,
+ * followed by UpdateBasisAxis. Width/height are assigned un-swapped (see SURVEY hazard 2). */
+FF_API void ff_camera_init_default(FfCamera* c, int width, int height);
+
+/* Camera::UpdateBasisAxis  utilities.h:407-418. */
+FF_API void ff_camera_update_basis(FfCamera* c);
+
+/* invView * invProj of kernel.cu:203 (lookAtRH, perspectiveFovRH_NO, two inverses, one mat*mat),
+ * hoisted out of the per-pixel path.  Exposed for tests. */
+FF_API void ff_camera_ray_matrix(const FfCamera* c, FfMat4* out_inv_view_times_inv_proj);
+
+/* ---- scene upload (kernel.cu:268-298) ---------------------------------------------------------- */
+
+/* Deep-copies `n` geometries (and the triangles / BXDFs they point to) to the device, flattened to
+ * 48-byte triangle records, per-geometry transform records and one object-space BVH per mesh.
+ * The host arrays are only read and may be freed after the call.  A second call replaces the scene
+ * and frees the previous one (the reference leaks it, kernel.cu:364-368).
+ * SPHERE geometries are rejected with FF_ERR_UNSUPPORTED. */
+FF_API int ff_upload_scene(FfState* state, const FfGeometry* host_geometries, int n);
+
+/* Host-only dry run of the scene compiler: sizes, BVH shape and a structural self-check.  Needs no GPU. */
+FF_API int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneInfo* out_info);
+
+/* ---- rendering (kernel.cu:335-344 + launchPathTrace kernel.cu:218-221) -------------------------- */
+
+/* Headless twin of the per-frame block.  Outputs (either may be NULL):
+ *   rgb8      W*H*3 bytes, row-major, top row first, exactly the PBO contents the viewer uploads
+ *             (kernel.cu:214; miss pixels stay 0 like the cudaMemset at kernel.cu:340)
+ *   radiance  W*H*3 floats, mean radiance per pixel before 8-bit quantisation
+ * `*_on_device` != 0 means the pointer is device memory of this state's device; otherwise it is host
+ * memory and the library copies back (PCIe-inclusive). */
+FF_API int ff_render(FfState* state, const FfCamera* camera, const FfRenderParams* params,
+                     void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device);
+
+/* Multi-GPU slice of the same frame: the image is cut into strips of `strip_rows` rows; this call
+ * renders the strips s with s % num_parts == part and writes them compacted, in increasing s, into
+ * rgb8/radiance (device or host as above), each local row W pixels wide.  part=0,num_parts=1 is
+ * ff_render.  The RNG is keyed on the GLOBAL pixel index, so the union over parts is bit-identical to
+ * the single-GPU image.  *out_local_rows receives the number of rows written (may be NULL). */
+FF_API int ff_render_strips(FfState* state, const FfCamera* camera, const FfRenderParams* params,
+                            int strip_rows, int part, int num_parts,
+                            void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device,
+                            int* out_local_rows);
+
+/* Number of rows ff_render_strips writes for (height, strip_rows, part, num_parts). */
+FF_API int ff_strips_local_rows(int height, int strip_rows, int part, int num_parts);
+
+/* Scatter gathered per-part compact buffers back to image order on the device:
+ * src holds, for part p = 0..num_parts-1 in order, that part's compact rows; elem_bytes is the size of
+ * one pixel (3 for rgb8, 12 for float3 radiance). */
+FF_API int ff_deinterleave_strips(FfState* state, const void* src_dev, void* dst_dev, int width, int height,
+                                  int strip_rows, int num_parts, int elem_bytes);
+
+/* Batch closest-hit query = intersectRays (kernel.cu:127-176) for `n` arbitrary world-space rays.
+ * rays/out are host arrays. trace_mode is an FfTraceMode. */
+FF_API int ff_intersect_rays(FfState* state, const FfRay* rays, int n, FfIntersect* out, int trace_mode);
+
+/* ---- OpenGL pixel-buffer interop (utilities.h:605-618, kernel.cu:335-344) ----------------------- */
+
+/* cudaGraphicsGLRegisterBuffer(&res, pbo, WriteDiscard) twin via hipGraphicsGLRegisterBuffer.
+ * The GL context that owns `pbo` must be current on the calling thread.  The buffer must hold
+ * width*height*3 bytes. */
+FF_API int ff_register_gl_pbo(FfState* state, unsigned int pbo, int width, int height);
+FF_API int ff_unregister_gl_pbo(FfState* state);
+
+/* map -> clear -> trace -> unmap  (kernel.cu:337-344).  params->width/height must match the registration. */
+FF_API int ff_render_to_pbo(FfState* state, const FfCamera* camera, const FfRenderParams* params);
+
+/* ---- measurement -------------------------------------------------------------------------------- */
+
+/* Turn per-launch node/triangle visit counters on (1) or off (0, default).  Ray counting is always on. */
+FF_API int ff_set_collect_stats(FfState* state, int on);
+FF_API int ff_stats(FfState* state, FfStats* out);
+
+/* ---- mesh loading (next-row scope: LoadMesh, utilities.h:781-840) ------------------------------- */
+
+/* Reads a Wavefront OBJ with LoadMesh's semantics: one FfTriangle per face from the face's first three
+ * indexed vertices; missing vt/vn yield zeros instead of the reference's out-of-bounds read.
+ * *out_triangles is malloc'ed by the library; release with ff_free_triangles. */
+FF_API int ff_load_obj(const char* path, FfTriangle** out_triangles, int* out_count);
+FF_API void ff_free_triangles(FfTriangle* triangles);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* FIREFLY_FF_API_H */

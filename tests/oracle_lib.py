@@ -1,0 +1,104 @@
+"""ctypes binding of oracle/libff_oracle.so — the CPU oracle (test infrastructure only; see oracle/ff_oracle.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from gpupathtracer_amd import types as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libff_oracle.so")
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("tri_tests", C.c_uint64), ("plane_tests", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_oracle():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libff_oracle.so"])
+    lib = C.CDLL(ORACLE_SO)
+    P, f32, i32 = C.POINTER, C.c_float, C.c_int
+    fp = P(f32)
+    lib.orc_mat4_mul.argtypes = [fp, fp, fp]
+    lib.orc_mat4_mul_vec4.argtypes = [fp, fp, fp]
+    lib.orc_mat4_inverse.argtypes = [fp, fp]
+    lib.orc_mat4_transpose.argtypes = [fp, fp]
+    lib.orc_translate.argtypes = [fp, fp, fp]
+    lib.orc_rotate.argtypes = [fp, f32, fp, fp]
+    lib.orc_scale.argtypes = [fp, fp, fp]
+    lib.orc_look_at_rh.argtypes = [fp, fp, fp, fp]
+    lib.orc_perspective_fov_rh_no.argtypes = [f32, f32, f32, f32, f32, fp]
+    lib.orc_radians.argtypes = [f32]
+    lib.orc_radians.restype = f32
+    lib.orc_normalize3.argtypes = [fp, fp]
+    lib.orc_cross3.argtypes = [fp, fp, fp]
+    lib.orc_dot3.argtypes = [fp, fp]
+    lib.orc_dot3.restype = f32
+    lib.orc_distance3.argtypes = [fp, fp]
+    lib.orc_distance3.restype = f32
+    lib.orc_geometry_init.argtypes = [P(T.FfGeometry), i32, T.FfVec3, T.FfVec3, T.FfVec3, P(T.FfTriangle), i32, f32]
+    lib.orc_geometry_init.restype = None
+    lib.orc_camera_update_basis.argtypes = [P(T.FfCamera)]
+    lib.orc_camera_init_default.argtypes = [P(T.FfCamera), i32, i32]
+    lib.orc_camera_ray_matrix.argtypes = [P(T.FfCamera), fp]
+    lib.orc_intersect_plane.argtypes = [P(T.FfGeometry), P(T.FfRay), P(T.FfIntersect)]
+    lib.orc_intersect_triangle.argtypes = [P(T.FfTriangle), P(T.FfRay), P(T.FfIntersect)]
+    lib.orc_intersect_rays.argtypes = [P(T.FfRay), P(T.FfGeometry), i32, P(T.FfIntersect)]
+    lib.orc_intersect_rays.restype = None
+    lib.orc_primary_ray.argtypes = [fp, P(T.FfCamera), i32, i32, P(T.FfRay)]
+    lib.orc_philox2x32_10.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_uint32), P(C.c_uint32)]
+    lib.orc_sample_uniforms.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp, fp, P(C.c_uint32)]
+    lib.orc_cosine_sample_hemisphere.argtypes = [f32, C.c_uint32, fp]
+    lib.orc_onb.argtypes = [fp, fp, fp]
+    lib.orc_render.argtypes = [P(T.FfGeometry), i32, P(T.FfCamera), P(T.FfRenderParams), i32, i32, i32, i32,
+                               C.c_void_p, C.c_void_p, P(OrcCounters), i32]
+    lib.orc_render.restype = None
+    _lib = lib
+    return lib
+
+
+def farr(values):
+    a = np.ascontiguousarray(values, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def oracle_render(scene, camera, params, window=None, threads=8, want_counters=False):
+    """Render `window` = (x0, y0, w, h) (default: whole image) with the CPU oracle -> (rgb8, radiance[, counters])."""
+    lib = load_oracle()
+    if window is None:
+        window = (0, 0, params.width, params.height)
+    x0, y0, w, h = window
+    rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+    rad = np.zeros((h, w, 3), dtype=np.float32)
+    ctr = OrcCounters()
+    lib.orc_render(scene.geometries, len(scene.geometries), C.byref(camera), C.byref(params), x0, y0, w, h,
+                   rgb8.ctypes.data, rad.ctypes.data, C.byref(ctr), threads)
+    if want_counters:
+        return rgb8, rad, ctr
+    return rgb8, rad
+
+
+def oracle_intersect(scene, origins, directions):
+    from gpupathtracer_amd.lib import INTERSECT_DTYPE
+    lib = load_oracle()
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    n = o.shape[0]
+    out = np.zeros(n, dtype=INTERSECT_DTYPE)
+    ray = T.FfRay()
+    isect = T.FfIntersect()
+    for i in range(n):
+        ray.m_origin = T.FfVec3(*o[i])
+        ray.m_direction = T.FfVec3(*d[i])
+        lib.orc_intersect_rays(C.byref(ray), scene.geometries, len(scene.geometries), C.byref(isect))
+        out[i] = np.frombuffer(bytes(isect), dtype=INTERSECT_DTYPE, count=1)[0]
+    return out
