@@ -683,12 +683,11 @@ hipError_t prepare_kernels()
 #define FF_SET_LDS(K)                                                                                                     \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudgetBytes); \
     if (e != hipSuccess) return e;
+    // Only the BVH kernels go past the 64 KiB default (node cache + stacks); the brute-force kernels use a 48 KiB batch
+    // buffer plus a little static LDS, and asking for the full 160 KiB on top of static LDS is rejected.
     FF_SET_LDS((trace_kernel<FF_TRACE_BVH, false>))
     FF_SET_LDS((trace_kernel<FF_TRACE_BVH, true>))
-    FF_SET_LDS((trace_kernel<FF_TRACE_BRUTE_FORCE, false>))
-    FF_SET_LDS((trace_kernel<FF_TRACE_BRUTE_FORCE, true>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
-    FF_SET_LDS((ray_batch_kernel<FF_TRACE_BRUTE_FORCE>))
 #undef FF_SET_LDS
     return hipSuccess;
 }
