@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path-tracing core.
+
+Metric (BASELINE.json): Mrays/s and ms/frame at 1920x1080, 8 bounces, 1024 spp on the wahoo+cube Cornell box
+(`configs[1]`), 1/2/4/8 GPUs.  One "step" = one full frame (every pixel, every sample) through the hot path;
+inputs (scene, camera) are resident in HBM before the timed region; outputs stay on the device (with N > 1 the
+finished strips are gathered to rank 0 over RCCL inside the timed region).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A ray = one closest-hit query (one path segment), counted on the device.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NODE_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 24  # algorithmic bytes per BVH node visit / triangle test / ray
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--camera", choices=["inside", "default"], default="inside",
+                    help="inside: (0,0,2.4) looking down -z, every primary ray hits the box (headline); "
+                         "default: the reference's literals kernel.cu:312-321 (camera 12.5 units outside, box covers ~4%% of the frame)")
+    ap.add_argument("--trace-mode", choices=["bvh", "brute"], default="bvh")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp-per-launch", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(st, width, rows, launches):
+    """sum over rays of (node bytes x nodes visited + triangle bytes x triangles tested + ray) plus
+    the framebuffer (float4 accumulate per extra launch, float3 radiance + rgb8 out)."""
+    fb = (12 + 3) * width * rows + 32 * width * rows * max(0, launches - 1)
+    return st.rays_traced * RAY_BYTES + st.nodes_visited * NODE_BYTES + st.tris_tested * TRI_BYTES + fb
+
+
+def cpu_baseline(scene, camera, args):
+    """The CPU oracle (a from-scratch port of the reference's brute-force loop; the reference has no CPU path) timed on
+    a bounded window of the same workload on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import oracle_render
+    from gpupathtracer_amd import lib
+
+    threads = max(1, min(16, os.cpu_count() or 1))
+    w, h, spp = 192, 108, 4
+    x0, y0 = (args.width - w) // 2, (args.height - h) // 2
+    params = lib.render_params(args.width, args.height, args.bounces, spp, args.seed)
+    t0 = time.perf_counter()
+    _, _, ctr = oracle_render(scene, camera, params, window=(x0, y0, w, h), threads=threads, want_counters=True)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(ctr.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"centre {w}x{h} window of the {args.width}x{args.height} frame, {args.bounces} bounces, {spp} spp, "
+                  f"brute force over {scene.triangle_count} triangles: {ctr.rays} rays in {dt:.2f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from gpupathtracer_amd import dist as ffdist
+    from gpupathtracer_amd import lib, scenes
+    from gpupathtracer_amd import types as T
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- inputs: resident before the timed region ----
+    scene = scenes.cornell_wahoo_scene()
+    if args.camera == "inside":
+        camera = scenes.posed_camera(args.width, args.height, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    else:
+        camera = scenes.default_camera(args.width, args.height)
+    mode = T.TRACE_BVH if args.trace_mode == "bvh" else T.TRACE_BRUTE_FORCE
+    params = lib.render_params(args.width, args.height, args.bounces, args.spp, args.seed, mode, T.SHADE_DIFFUSE_PATH,
+                               T.GRID_FULL, args.spp_per_launch)
+    tracer = lib.Tracer(local_rank)
+    tracer.upload_scene(scene)
+    tracer.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    strip_rows = ffdist.STRIP_ROWS if world > 1 else args.height
+    local_rows = tracer.strips_local_rows(args.height, strip_rows, rank, world)
+    rgb8 = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.uint8, device=device)
+    rad = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.float32, device=device)
+    full_rgb8 = torch.empty((args.height, args.width, 3), dtype=torch.uint8, device=device) if rank == 0 and world > 1 else None
+    full_rad = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 and world > 1 else None
+
+    def step():
+        tracer.render_strips_device(camera, params, strip_rows, rank, world, rgb8.data_ptr(), rad.data_ptr())
+        if world > 1:
+            # framebuffer gather over RCCL/xGMI to the rank that owns the display buffer, then strip de-interleave
+            g8 = ffdist.gather_strips(rgb8[:local_rows], args.height, strip_rows, rank, world, dist)
+            gr = ffdist.gather_strips(rad[:local_rows], args.height, strip_rows, rank, world, dist)
+            if rank == 0:
+                tracer.deinterleave_strips(g8.data_ptr(), full_rgb8.data_ptr(), args.width, args.height, strip_rows, world, 3)
+                tracer.deinterleave_strips(gr.data_ptr(), full_rad.data_ptr(), args.width, args.height, strip_rows, world, 12)
+        return tracer.stats()
+
+    # ---- warmup (untimed); the first warmup frame also collects the node/triangle visit counters ----
+    tracer.set_collect_stats(True)
+    counted = step()
+    tracer.set_collect_stats(False)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
+    barrier_sync()
+    t0 = time.perf_counter()
+    rays = 0
+    kernel_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st.rays_traced
+        kernel_ms += st.kernel_ms
+        launches += st.kernel_launches
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        agg = torch.tensor([float(rays), kernel_ms, float(counted.rays_traced), float(counted.nodes_visited), float(counted.tris_tested)],
+                           dtype=torch.float64, device=device)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        total_rays = agg[0].item()
+    else:
+        total_rays = float(rays)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays / elapsed / 1e6
+        # roofline of the dominant kernel (trace_kernel) on this rank: algorithmic bytes per launch / mean launch duration
+        algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, counted.kernel_launches) / max(1, counted.kernel_launches)
+        mean_launch_s = kernel_ms / max(1, launches) / 1e3
+        achieved = algo_bytes_launch / mean_launch_s / 1e9
+        out = {
+            "metric": "Mrays/s (path segments = closest-hit queries, device-counted) at 1080p, 8 bounces, 1024 spp",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "frames_per_s": round(1e3 / ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"C2 wahoo.obj+cube.obj Cornell box (5184 triangles, 6 planes), {args.width}x{args.height}, "
+                            f"{args.bounces} bounces, {args.spp} spp, camera={args.camera}, trace={args.trace_mode}, seed {args.seed}",
+                "rays_per_frame": int(total_rays / args.steps), "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "trace_kernel<BVH>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
+                "algorithmic_bytes_per_launch": int(algo_bytes_launch),
+                "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
+                            "tris": round(counted.tris_tested / max(1, counted.rays_traced), 3)},
+                "note": "algorithmic bytes are served from LDS/L1/L2 (scene = 0.4 MB); HBM traffic is in profiles/ (PMC)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, camera, args)
+        print(json.dumps(out), flush=True)
+
+    tracer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Multi-GPU frame rendering: one process per GPU, image strips dealt round-robin to ranks, one framebuffer gather.
+
+The path shards with no exchange during rendering (pixels are independent, the scene is replicated, and the RNG is
+keyed on the global pixel index), so the only collective is the gather of the finished strips to rank 0 — the rank
+that would own the GL pixel buffer in the viewer.  `torch.distributed` is plumbing here: backend "nccl" is RCCL over
+xGMI on the GPU box, "gloo" on CPU for the tests.
+"""
+import numpy as np
+
+STRIP_ROWS = 16  # the reference's block height (kernel.cu:306); strips of 16 rows are dealt round-robin to ranks
+
+
+def strip_layout(height, strip_rows, num_parts):
+    """rows owned by each part, in part order (mirrors ff_strips_local_rows)."""
+    nstrips = (height + strip_rows - 1) // strip_rows
+    rows = []
+    for part in range(num_parts):
+        r = 0
+        for s in range(part, nstrips, num_parts):
+            y0 = s * strip_rows
+            r += strip_rows if y0 + strip_rows <= height else height - y0
+        rows.append(r)
+    return rows
+
+
+def strip_row_indices(height, strip_rows, part, num_parts):
+    """global row index of every local row of `part` (in local order)."""
+    nstrips = (height + strip_rows - 1) // strip_rows
+    idx = []
+    for s in range(part, nstrips, num_parts):
+        y0 = s * strip_rows
+        idx.extend(range(y0, min(y0 + strip_rows, height)))
+    return np.asarray(idx, dtype=np.int64)
+
+
+def gather_strips(local, height, strip_rows, rank, world_size, dist=None, dst=0):
+    """Gather every rank's compact strip block (torch tensor [local_rows, W, C]) to `dst`.
+
+    Returns on `dst` a tensor [sum(rows), W, C] holding the parts' blocks back to back in part order (the layout
+    ff_deinterleave_strips expects), on other ranks None.  Blocks are padded to the largest part for the collective.
+    """
+    import torch
+
+    rows = strip_layout(height, strip_rows, world_size)
+    if world_size == 1:
+        return local
+    max_rows = max(rows)
+    padded = local
+    if local.shape[0] != max_rows:
+        padded = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    if rank == dst:
+        bucket = [torch.empty_like(padded) for _ in range(world_size)]
+        dist.gather(padded, gather_list=bucket, dst=dst)
+        return torch.cat([bucket[p][: rows[p]] for p in range(world_size)], dim=0)
+    dist.gather(padded, gather_list=None, dst=dst)
+    return None
+
+
+def deinterleave_host(blocks, height, strip_rows, num_parts):
+    """CPU/torch twin of ff_deinterleave_strips for tests: [sum(rows), W, C] part-major -> [H, W, C] image order."""
+    import torch
+
+    out = torch.empty((height,) + tuple(blocks.shape[1:]), dtype=blocks.dtype, device=blocks.device)
+    off = 0
+    for part in range(num_parts):
+        idx = torch.from_numpy(strip_row_indices(height, strip_rows, part, num_parts)).to(blocks.device)
+        out[idx] = blocks[off: off + len(idx)]
+        off += len(idx)
+    return out
