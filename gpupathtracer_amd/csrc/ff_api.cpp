@@ -2,6 +2,7 @@
 // interop and measurement.  Host side of the seam the reference has at kernel.cu:268-298 (upload) and
 // kernel.cu:335-344 (per-frame map -> clear -> kernel -> unmap).
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -23,7 +24,7 @@ struct FfState {
     GeomRecord* d_geoms = nullptr;
     TriRecord* d_tris = nullptr;
     BvhNode* d_nodes = nullptr;
-    int num_geoms = 0, num_nodes = 0, max_depth = 0;
+    int num_geoms = 0, num_planes = 0, num_nodes = 0, max_depth = 0;
     uint64_t num_tris = 0;
     bool has_scene = false;
     // work buffers (device)
@@ -37,6 +38,7 @@ struct FfState {
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
+    int block_threads = kBlockThreads; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
     FfStats stats;
     // GL interop
     hipGraphicsResource* pbo_resource = nullptr;
@@ -145,11 +147,14 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.key = (unsigned)prm->seed ^ (unsigned)(prm->seed >> 32);
     k.shade_mode = prm->shade_mode;
     k.num_geoms = s->num_geoms;
+    k.num_planes = s->num_planes;
     k.geoms = s->d_geoms;
     k.tris = s->d_tris;
     k.nodes = s->d_nodes;
+    const int block_threads = prm->trace_mode == FF_TRACE_BVH ? s->block_threads : kBlockThreads;
     k.stack_depth = s->max_depth + 2;
-    k.lds_nodes = s->num_nodes < max_lds_nodes(k.stack_depth) ? s->num_nodes : max_lds_nodes(k.stack_depth);
+    const int fit = max_lds_nodes(k.stack_depth, block_threads, s->num_geoms);
+    k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;
     if (k.lds_nodes < 0) k.lds_nodes = 0;
     k.accum = s->d_accum;
     k.rgb8 = rgb8_dev;
@@ -159,7 +164,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
 
     const int blocks_per_cu = prm->trace_mode == FF_TRACE_BVH ? 1 : 2;
     int grid = s->num_cus * blocks_per_cu;
-    const uint64_t max_useful = (k.total_items + (uint64_t)kBlockThreads - 1) / (uint64_t)kBlockThreads;
+    const uint64_t max_useful = (k.total_items + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
 
@@ -175,7 +180,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
         k.first_chunk = l == 0;
         k.last_chunk = l == launches - 1;
         FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
-        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, st));
+        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st));
     }
     FF_HIP(hipEventRecord(s->ev_end, st));
     FF_HIP(hipStreamSynchronize(st));
@@ -214,6 +219,10 @@ int ff_create(FfState** out_state, int device_id)
     if (!s) return fail(FF_ERR_OOM, "ff_create: out of host memory");
     s->device = device_id;
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* bt = std::getenv("FF_BLOCK_THREADS")) {
+        const int v = std::atoi(bt);
+        if (v == 512 || v == 1024) s->block_threads = v;
+    }
     hipError_t pe = prepare_kernels();
     if (pe != hipSuccess) {
         delete s;
@@ -274,6 +283,8 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     s->num_geoms = (int)cs.geoms.size();
+    s->num_planes = 0;
+    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type == FF_GEOM_PLANE ? 1 : 0;
     s->num_nodes = (int)cs.nodes.size();
     s->num_tris = cs.tris.size();
     s->max_depth = cs.max_depth;
@@ -303,6 +314,8 @@ int ff_render_strips(FfState* s, const FfCamera* camera, const FfRenderParams* p
     int st = check_params(params);
     if (st != FF_OK) return st;
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render: no scene uploaded");
+    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
+        return fail(FF_ERR_UNSUPPORTED, "BVH mode keeps geometry records in LDS and supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (strip_rows <= 0 || num_parts <= 0 || part < 0 || part >= num_parts) return fail(FF_ERR_INVALID_ARG, "ff_render_strips: bad strip partition (%d rows, part %d of %d)", strip_rows, part, num_parts);
     FF_HIP(hipSetDevice(s->device));
     const int local_rows = ff_strips_local_rows(params->height, strip_rows, part, num_parts);
@@ -375,11 +388,13 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.out = d_out;
     p.n = n;
     p.num_geoms = s->num_geoms;
+    p.num_planes = s->num_planes;
     p.geoms = s->d_geoms;
     p.tris = s->d_tris;
     p.nodes = s->d_nodes;
     p.stack_depth = s->max_depth + 2;
-    p.lds_nodes = s->num_nodes < max_lds_nodes(p.stack_depth) ? s->num_nodes : max_lds_nodes(p.stack_depth);
+    const int fit = max_lds_nodes(p.stack_depth, kBlockThreads, s->num_geoms);
+    p.lds_nodes = s->num_nodes < fit ? s->num_nodes : (fit > 0 ? fit : 0);
     e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);

@@ -56,14 +56,17 @@ struct GeomRecord {
     float plane_n[4];                                 // m_normal (utilities.h:229)
     float albedo[4];                                  // BXDF::m_albedo
     float emission[4];                                // BXDF::m_emissiveColor * m_intensity (utilities.h:102)
+    float wmin[4], wmax[4];                           // world-space AABB of the geometry, conservatively padded (pruning only)
     int32_t type;                                     // FfGeometryType
     int32_t bxdf_type;                                // FfBXDFType
     int32_t tri_first;                                // first TriRecord of this mesh
     int32_t tri_count;
     int32_t bvh_root;                                 // inner-node index of this mesh's root, -1 if none
-    int32_t pad[3];
+    int32_t orig_index;                               // index i in the caller's Geometry[] (kernel.cu:151,162); records are
+                                                      // stored in PROCESSING order: planes first, then meshes
+    int32_t pad[2];
 };
-static_assert(sizeof(GeomRecord) == 14 * 16 + 32, "GeomRecord layout");
+static_assert(sizeof(GeomRecord) == 16 * 16 + 32, "GeomRecord layout");
 
 struct CompiledScene {
     std::vector<GeomRecord> geoms;

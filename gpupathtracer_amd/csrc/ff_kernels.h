@@ -7,8 +7,10 @@
 
 namespace ff {
 
-constexpr int kBlockThreads = 512;        // 8 waves per workgroup, one workgroup per CU shares one LDS copy of the BVH top
+constexpr int kBlockThreads = 512;        // default workgroup: 8 waves, one workgroup per CU shares one LDS copy of the BVH top
+constexpr int kBlockThreadsMax = 1024;    // alternative: 16 waves per workgroup (4 per SIMD), smaller node cache next to the stacks
 constexpr int kLdsBudgetBytes = 160 * 1024;
+constexpr int kMaxGeometriesBvh = 128;    // geometry records are resident in LDS in BVH mode (288 B each)
 constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
 
 // Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).
@@ -31,6 +33,7 @@ struct KParams {
     int first_chunk, last_chunk;
     // scene
     int num_geoms;
+    int num_planes;  // records [0, num_planes) are planes, the rest meshes (processing order)
     const GeomRecord* geoms;
     const TriRecord* tris;
     const BvhNode* nodes;
@@ -49,6 +52,7 @@ struct RayBatchParams {
     FfIntersect* out;
     int n;
     int num_geoms;
+    int num_planes;
     const GeomRecord* geoms;
     const TriRecord* tris;
     const BvhNode* nodes;
@@ -57,11 +61,12 @@ struct RayBatchParams {
 };
 
 // LDS bytes the BVH kernels need for (lds_nodes, stack_depth).
-size_t bvh_lds_bytes(int lds_nodes, int stack_depth);
+size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms);
 // Largest node count that fits LDS next to a stack of `stack_depth` entries per lane.
-int max_lds_nodes(int stack_depth);
+int max_lds_nodes(int stack_depth, int block_threads, int num_geoms);
 
-hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, hipStream_t stream);
+// block_threads: 512 or 1024 for the BVH kernel; the brute-force kernel always runs 512.
+hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream);
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream);
 hipError_t launch_deinterleave(const void* src, void* dst, int width, int height, int strip_rows, int num_parts, int elem_bytes,
                                hipStream_t stream);

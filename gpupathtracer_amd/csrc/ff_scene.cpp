@@ -316,6 +316,34 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
         r.type = g.m_geometryType;
         r.bxdf_type = b.m_type;
         r.bvh_root = -1;
+        r.orig_index = i;
+        // object-space bounds -> world AABB (pruning only, padded below)
+        float omn[3] = { -0.5f, -0.5f, 0.f }, omx[3] = { 0.5f, 0.5f, 0.f }; // unit plane quad, kernel.cu:18
+        if (g.m_geometryType == FF_GEOM_TRIANGLEMESH) {
+            Box ob;
+            ob.reset();
+            const int cnt0 = g.m_triangles ? g.m_numberOfTriangles : 0;
+            for (int t = 0; t < cnt0; ++t) {
+                ob.grow(&g.m_triangles[t].m_v0.x);
+                ob.grow(&g.m_triangles[t].m_v1.x);
+                ob.grow(&g.m_triangles[t].m_v2.x);
+            }
+            for (int k = 0; k < 3; ++k) { omn[k] = ob.mn[k]; omx[k] = ob.mx[k]; }
+        }
+        Box wb;
+        wb.reset();
+        if (omn[0] <= omx[0]) {
+            for (int c = 0; c < 8; ++c) {
+                const V4 pw = mul(mod, v4((c & 1) ? omx[0] : omn[0], (c & 2) ? omx[1] : omn[1], (c & 4) ? omx[2] : omn[2], 1.f));
+                wb.grow(&pw.x);
+            }
+            float big = 0.f;
+            for (int k = 0; k < 3; ++k) big = std::max(big, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + (wb.mx[k] - wb.mn[k]));
+            const float wpad = 1e-4f * big + 1e-4f;
+            for (int k = 0; k < 3; ++k) { r.wmin[k] = wb.mn[k] - wpad; r.wmax[k] = wb.mx[k] + wpad; }
+        } else { // empty mesh: a box no ray can enter
+            for (int k = 0; k < 3; ++k) { r.wmin[k] = 3.0e38f; r.wmax[k] = 3.0e38f; }
+        }
         if (g.m_geometryType == FF_GEOM_TRIANGLEMESH) {
             const int cnt = g.m_triangles ? g.m_numberOfTriangles : 0;
             if (cnt < 0) return fail(FF_ERR_INVALID_ARG, "geometry %d: negative triangle count", i);
@@ -329,6 +357,11 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
             out.total_tris += (uint64_t)cnt;
         }
     }
+    // Processing order: planes first (cheap, they tighten the distance bound), then meshes; stable within each class.
+    // The closest hit does not depend on this order: ties are broken on orig_index exactly like the reference's loop.
+    std::stable_sort(out.geoms.begin(), out.geoms.end(), [](const GeomRecord& a, const GeomRecord& b) {
+        return (a.type == FF_GEOM_PLANE) > (b.type == FF_GEOM_PLANE);
+    });
     return FF_OK;
 }
 
@@ -337,8 +370,8 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
 // ---- host-only dry run + structural self-check -------------------------------------------------------------------
 
 namespace ff {
-size_t bvh_lds_bytes(int lds_nodes, int stack_depth);
-int max_lds_nodes(int stack_depth);
+size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms);
+int max_lds_nodes(int stack_depth, int block_threads, int num_geoms);
 
 namespace {
 
@@ -425,8 +458,8 @@ extern "C" int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneIn
     out->bvh_max_depth = cs.max_depth;
     out->num_triangles = cs.tris.size();
     const int stack_depth = cs.max_depth + 2;
-    out->lds_nodes = std::min((int)cs.nodes.size(), std::max(0, max_lds_nodes(stack_depth)));
-    out->lds_bytes = (int)bvh_lds_bytes(out->lds_nodes, stack_depth);
+    out->lds_nodes = std::min((int)cs.nodes.size(), std::max(0, max_lds_nodes(stack_depth, 512, (int)cs.geoms.size())));
+    out->lds_bytes = (int)bvh_lds_bytes(out->lds_nodes, stack_depth, 512, (int)cs.geoms.size());
     out->device_bytes = cs.geoms.size() * sizeof(GeomRecord) + cs.tris.size() * sizeof(TriRecord) + cs.nodes.size() * sizeof(BvhNode);
     int max_leaf = 0;
     out->valid = check_bvh(cs, &max_leaf) ? 1 : 0;
