@@ -1,0 +1,167 @@
+"""CPU-only checks of the product library: it loads, exports every symbol of include/firefly/ff_api.h, keeps the
+reference's struct layouts, reports errors as status codes (never exit()), and its host-side pieces (scene compiler,
+OBJ reader) behave.  No compute call is made here; without a GPU ff_create must fail loudly."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gpupathtracer_amd import scenes
+from gpupathtracer_amd import types as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_RES = "/root/reference/sceneResources"
+
+
+def test_library_exports_every_declared_symbol(ff):
+    lib = ff.load()
+    header = open(os.path.join(ROOT, "include", "firefly", "ff_api.h")).read()
+    declared = set(re.findall(r"FF_API\s+[\w\s\*]+?\b(ff_\w+)\s*\(", header))
+    assert declared == set(ff.EXPORTS), declared ^ set(ff.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ff_version() >= 100
+
+
+def test_struct_layouts_match_reference_sizes():
+    # g++ x86-64 sizes of the reference's structs
+    assert (C.sizeof(T.FfTriangle), C.sizeof(T.FfGeometry), C.sizeof(T.FfCamera), C.sizeof(T.FfRay), C.sizeof(T.FfIntersect),
+            C.sizeof(T.FfBXDF)) == (96, 208, 108, 24, 40, 60)
+    assert T.FfGeometry.m_triangles.offset == 184 and T.FfGeometry.m_numberOfTriangles.offset == 192 and T.FfGeometry.m_bxdf.offset == 200
+    assert T.FfGeometry.m_modelMatrix.offset == 40 and T.FfGeometry.m_inverseModelMatrix.offset == 104
+    assert T.FfCamera.m_yaw.offset == 60 and T.FfCamera.m_cameraFirstMouseInput.offset == 96 and T.FfCamera.m_xDelta.offset == 100
+    assert T.FfIntersect.m_hit.offset == 28 and T.FfIntersect.geometryIndex.offset == 32
+
+
+def test_bxdf_defaults(ff):
+    b = T.FfBXDF()
+    ff.load().ff_bxdf_init(C.byref(b))
+    assert b.m_type == T.BXDF_COUNT and b.m_albedo.tuple() == (-1, -1, -1) and b.m_intensity == -1  # utilities.h:81-88
+
+
+def test_no_gpu_means_loud_failure_or_working_device(ff):
+    lib = ff.load()
+    st = C.c_void_p()
+    rc = lib.ff_create(C.byref(st), 0)
+    if rc == T.FF_OK:  # running on a GPU box
+        lib.ff_destroy(st)
+        return
+    assert rc in (T.FF_ERR_NO_DEVICE, T.FF_ERR_HIP)
+    assert lib.ff_last_error()  # a message, not an exit()
+    with pytest.raises(ff.FireflyError):
+        ff.Tracer(0)
+
+
+def test_null_and_invalid_arguments_are_status_codes(ff):
+    lib = ff.load()
+    assert lib.ff_create(None, 0) == T.FF_ERR_INVALID_ARG
+    assert lib.ff_upload_scene(None, None, 0) == T.FF_ERR_INVALID_ARG
+    assert lib.ff_render(None, None, None, None, 0, None, 0) == T.FF_ERR_INVALID_ARG
+    assert lib.ff_stats(None, None) == T.FF_ERR_INVALID_ARG
+    assert lib.ff_destroy(None) == T.FF_OK
+    assert lib.ff_scene_info(None, 0, None) == T.FF_ERR_INVALID_ARG
+    info = T.FfSceneInfo()
+    assert lib.ff_scene_info(None, 0, C.byref(info)) == T.FF_ERR_INVALID_ARG
+    assert b"no geometries" in lib.ff_last_error()
+
+
+def test_unsupported_and_malformed_scenes(ff):
+    lib = ff.load()
+    info = T.FfSceneInfo()
+    # SPHERE: the reference only printf's (kernel.cu:166-169)
+    g = (T.FfGeometry * 1)()
+    lib.ff_geometry_init(C.byref(g[0]), T.GEOM_SPHERE, T.FfVec3(), T.FfVec3(), T.FfVec3(1, 1, 1), None, 0, 2.0)
+    assert g[0].m_sphereRadius == 2.0
+    bx = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 1, 1))
+    g[0].m_bxdf = C.pointer(bx)
+    assert lib.ff_scene_info(g, 1, C.byref(info)) == T.FF_ERR_UNSUPPORTED
+    # null BXDF: the reference memcpy's from it unconditionally (kernel.cu:282)
+    lib.ff_geometry_init(C.byref(g[0]), T.GEOM_PLANE, T.FfVec3(), T.FfVec3(), T.FfVec3(1, 1, 1), None, 0, 0.0)
+    assert lib.ff_scene_info(g, 1, C.byref(info)) == T.FF_ERR_INVALID_ARG
+    # non-affine model matrix
+    g[0].m_bxdf = C.pointer(bx)
+    g[0].m_inverseModelMatrix.m[3] = 0.25
+    assert lib.ff_scene_info(g, 1, C.byref(info)) == T.FF_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name,builder,tris,planes", [
+    ("c1", lambda: scenes.reference_scene(scenes.load_mesh("cube")), 12, 4),
+    ("c2", scenes.cornell_wahoo_scene, 5172 + 12, 6),
+    ("c3", scenes.blooper_scene, 6036 + 12, 2),
+    ("sphere_l2", lambda: scenes.sphere_stress_scene(2), 960 * 16, 6),
+])
+def test_scene_compiler_self_check(ff, name, builder, tris, planes):
+    info = ff.scene_info(builder())
+    assert info.valid == 1
+    assert info.num_triangles == tris and info.num_planes == planes
+    assert 1 <= info.bvh_max_leaf <= 4
+    assert info.bvh_max_depth <= 30
+    assert info.lds_bytes <= 160 * 1024 and 0 < info.lds_nodes <= info.bvh_nodes
+
+
+def test_scene_compiler_edge_cases(ff):
+    red = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0))
+    one = np.zeros((1, 24), dtype=np.float32)
+    one[0, :9] = [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    s = scenes.Scene().add_mesh(one, bxdf=red).add_mesh(np.zeros((0, 24), np.float32), bxdf=red).add_plane(bxdf=red).finalize()
+    info = ff.scene_info(s)
+    assert info.valid == 1 and info.num_triangles == 1 and info.num_meshes == 2 and info.bvh_nodes == 1
+    # degenerate: many identical triangles (SAH cannot separate them -> median splits, bounded depth)
+    same = np.repeat(one, 300, axis=0)
+    info = ff.scene_info(scenes.Scene().add_mesh(same, bxdf=red).finalize())
+    assert info.valid == 1 and info.num_triangles == 300 and info.bvh_max_leaf <= 4 and info.bvh_max_depth <= 30
+
+
+def test_subdivided_sphere_is_deterministic_and_on_the_sphere():
+    base = scenes.load_mesh("sphereBlender")
+    a, b = scenes.subdivide_sphere(base, 2), scenes.subdivide_sphere(base, 2)
+    assert a.shape == (960 * 16, 24) and np.array_equal(a, b)
+    r = np.linalg.norm(a[:, :9].reshape(-1, 3), axis=1)
+    assert np.abs(r - 1).max() < 1e-6
+
+
+def test_obj_loader_handwritten(ff):
+    tris = ff.load_obj(os.path.join(ROOT, "tests", "data", "quad_mixed.obj"))
+    assert tris.shape == (5, 24)
+    # f 1/1/1 2/2/1 3/3/1
+    assert tris[0, :9].tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0]
+    assert tris[0, 9:15].tolist() == [0, 0, 1, 0, 1, 1] and tris[0, 15:].tolist() == [0, 0, 1] * 3
+    # quad 1 2 3 4 -> (1,2,3), (1,3,4); no vt/vn -> zeros (the reference reads out of bounds here, utilities.h:823-824)
+    assert tris[1, :9].tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0] and tris[2, :9].tolist() == [0, 0, 0, 1, 1, 0, 0, 1, 0]
+    assert not tris[1, 9:].any()
+    # negative indices: -1 -> v5, -5 -> v1, -4 -> v2; v//vn corners
+    assert tris[3, :9].tolist() == [0.5, 0.5, 1.25, 0, 0, 0, 1, 0, 0] and tris[3, 15:18].tolist() == [0, 1, 0]
+    # mixed corner forms on one face
+    assert tris[4, :9].tolist() == [0.5, 0.5, 1.25, 0, 0, 0, 1, 0, 0] and tris[4, 11:13].tolist() == [1, 0] and tris[4, 21:].tolist() == [0, 1, 0]
+
+
+def test_obj_loader_errors(ff, tmp_path):
+    with pytest.raises(ff.FireflyError) as e:
+        ff.load_obj(str(tmp_path / "missing.obj"))
+    assert e.value.status == T.FF_ERR_IO
+    p = tmp_path / "empty.obj"
+    p.write_text("# nothing\nv 0 0 0\n")
+    with pytest.raises(ff.FireflyError) as e:
+        ff.load_obj(str(p))
+    assert e.value.status == T.FF_ERR_IO
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_RES), reason="reference assets are only mounted in the build container")
+@pytest.mark.parametrize("name", ["cube", "wahoo", "rocketman", "sphereBlender", "sphere"])
+def test_obj_loader_matches_reference_tinyobj(ff, name):
+    """ff_load_obj vs the fixture the reference's own tiny_obj_loader.h produced (oracle/ref_tinyobj_dump.cpp), bit for bit."""
+    mine = ff.load_obj(os.path.join(REF_RES, name + ".obj"))
+    ref = scenes.load_mesh(name)
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+
+
+def test_strip_rows_helper(ff):
+    lib = ff.load()
+    for h, sr, n in [(1080, 16, 8), (1080, 16, 1), (17, 16, 4), (2160, 16, 8), (5, 16, 3)]:
+        rows = [lib.ff_strips_local_rows(h, sr, p, n) for p in range(n)]
+        assert sum(rows) == h
+    assert lib.ff_strips_local_rows(1080, 16, 0, 8) == 9 * 16 and lib.ff_strips_local_rows(1080, 16, 3, 8) == 8 * 16 + 8
+    assert lib.ff_strips_local_rows(0, 16, 0, 1) == 0 and lib.ff_strips_local_rows(10, 0, 0, 1) == 0
