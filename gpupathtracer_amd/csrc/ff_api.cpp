@@ -1,6 +1,7 @@
 // ff_api.cpp — the C ABI (include/firefly/ff_api.h): tracer state, scene upload, frame rendering, HIP-GL pixel-buffer
 // interop and measurement.  Host side of the seam the reference has at kernel.cu:268-298 (upload) and
 // kernel.cu:335-344 (per-frame map -> clear -> kernel -> unmap).
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +39,8 @@ struct FfState {
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
-    int block_threads = kBlockThreads; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
+    int block_threads = kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
+    int setup_threshold = 24, leaf_threshold = 16; // BVH kernel scheduling knobs (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
     // GL interop
     hipGraphicsResource* pbo_resource = nullptr;
@@ -146,6 +148,8 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.spp_total = spp;
     k.key = (unsigned)prm->seed ^ (unsigned)(prm->seed >> 32);
     k.shade_mode = prm->shade_mode;
+    k.setup_threshold = s->setup_threshold;
+    k.leaf_threshold = s->leaf_threshold;
     k.num_geoms = s->num_geoms;
     k.num_planes = s->num_planes;
     k.geoms = s->d_geoms;
@@ -221,8 +225,10 @@ int ff_create(FfState** out_state, int device_id)
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* bt = std::getenv("FF_BLOCK_THREADS")) {
         const int v = std::atoi(bt);
-        if (v == 512 || v == 1024) s->block_threads = v;
+        if (v == 512 || v == 768 || v == 1024) s->block_threads = v;
     }
+    if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) s->setup_threshold = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_LEAF_THRESHOLD")) s->leaf_threshold = std::max(1, std::min(64, std::atoi(e)));
     hipError_t pe = prepare_kernels();
     if (pe != hipSuccess) {
         delete s;
@@ -315,7 +321,7 @@ int ff_render_strips(FfState* s, const FfCamera* camera, const FfRenderParams* p
     if (st != FF_OK) return st;
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render: no scene uploaded");
     if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
-        return fail(FF_ERR_UNSUPPORTED, "BVH mode keeps geometry records in LDS and supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
+        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (strip_rows <= 0 || num_parts <= 0 || part < 0 || part >= num_parts) return fail(FF_ERR_INVALID_ARG, "ff_render_strips: bad strip partition (%d rows, part %d of %d)", strip_rows, part, num_parts);
     FF_HIP(hipSetDevice(s->device));
     const int local_rows = ff_strips_local_rows(params->height, strip_rows, part, num_parts);
@@ -373,6 +379,8 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     if (n < 0) return fail(FF_ERR_INVALID_ARG, "ff_intersect_rays: negative count");
     if (trace_mode != FF_TRACE_BRUTE_FORCE && trace_mode != FF_TRACE_BVH) return fail(FF_ERR_INVALID_ARG, "unknown trace_mode %d", trace_mode);
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_intersect_rays: no scene uploaded");
+    if (trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
+        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (n == 0) return FF_OK;
     FF_HIP(hipSetDevice(s->device));
     FfRay* d_rays = nullptr;

@@ -10,7 +10,7 @@ namespace ff {
 constexpr int kBlockThreads = 512;        // default workgroup: 8 waves, one workgroup per CU shares one LDS copy of the BVH top
 constexpr int kBlockThreadsMax = 1024;    // alternative: 16 waves per workgroup (4 per SIMD), smaller node cache next to the stacks
 constexpr int kLdsBudgetBytes = 160 * 1024;
-constexpr int kMaxGeometriesBvh = 128;    // geometry records are resident in LDS in BVH mode (288 B each)
+constexpr int kMaxGeometriesBvh = 64;     // BVH mode: one candidate bit per geometry, records resident in LDS (288 B each)
 constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
 
 // Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).
@@ -31,6 +31,9 @@ struct KParams {
     unsigned key;       // Philox key (seed folded to 32 bits)
     int shade_mode;
     int first_chunk, last_chunk;
+    // BVH kernel scheduling knobs: lanes waiting for setup run it together once this many have gathered; a leaf step runs
+    // once this many lanes hold a leaf (both also run as soon as nothing else can make progress)
+    int setup_threshold, leaf_threshold;
     // scene
     int num_geoms;
     int num_planes;  // records [0, num_planes) are planes, the rest meshes (processing order)

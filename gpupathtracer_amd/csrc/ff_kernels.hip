@@ -3,21 +3,23 @@
 // What the reference runs per pixel (kernel.cu:186-221: primary ray, brute-force closest hit over all geometries and
 // triangles, shade, 8-bit store) is restructured here as a persistent mega-kernel:
 //
-//   * one workgroup of 512 threads per CU; the top of the BVH node array is staged ONCE per workgroup into LDS
-//     (64-byte nodes, both child boxes per node) and every lane keeps its traversal stack in LDS (lane-strided, so
+//   * one workgroup per CU; the top of the BVH node array and all geometry records are staged ONCE per workgroup into
+//     LDS (64-byte nodes, both child boxes per node) and every lane keeps its traversal stack in LDS (lane-strided, so
 //     stack pushes/pops are bank-conflict free);
-//   * lanes pull (pixel) work items from one global counter with a wave-wide ballot + prefix compaction, so a lane
-//     whose paths have all terminated is refilled immediately instead of idling until its wave finishes;
-//   * each loop iteration advances every live lane by one path segment (closest-hit query + shading); terminated
-//     paths regenerate in place (next sample of the same pixel), which keeps the 64 lanes busy across bounces;
+//   * lanes pull (pixel) work items from one global counter with a wave-wide ballot + prefix compaction, and a lane
+//     owns its pixel for all samples: terminated paths regenerate in place;
+//   * the BVH kernel is a per-lane state machine: lanes whose ray has finished traversal wait until enough of them
+//     have gathered (or nobody is traversing any more), then resolve/shade/spawn their next ray TOGETHER while the
+//     unfinished lanes keep their traversal state; traversal itself alternates inner-node and leaf steps wave-wide.
+//     This keeps the 64 lanes of a wave occupied although neighbouring rays need very different amounts of work;
 //   * the per-pixel camera matrix work of kernel.cu:203 is hoisted to the host; the per-hit 4x4 inverse of
 //     kernel.cu:117 is hoisted to the scene compiler.
 //
 // Numerics: the file is compiled with -ffp-contract=off and IEEE-correct sqrt/divide.  Every value that decides or
 // becomes part of a hit (object-space ray, Möller-Trumbore, world point, world distance, normal) is computed with
 // the reference's / glm's exact operation order, so hits are bit-identical to the brute-force reference loop.  Only
-// the BVH box tests use fused multiply-adds and an approximate reciprocal: they prune conservatively and never feed
-// a result.
+// pruning (box tests, candidate screening) uses fused multiply-adds and approximate reciprocals, always with explicit
+// margins: it can skip work that cannot matter, it never feeds a result.
 #include "ff_kernels.h"
 
 namespace ff {
@@ -33,7 +35,7 @@ struct Ray {
     float ox, oy, oz, dx, dy, dz;
 };
 
-// Closest hit so far.  rec = TriRecord index for triangles, -1 for planes.
+// Closest hit.  rec = TriRecord index for triangles, -1 for planes; (px,py,pz) = world-space hit point.
 struct Best {
     float dist;
     int geom;
@@ -41,8 +43,16 @@ struct Best {
     float px, py, pz;
 };
 
+// What a query carries while it is in flight: the exact distance and identity of the best resolved candidate.  The hit
+// point is produced once, at the end (finish_segment), to keep three registers out of the traversal loop.
+struct BestId {
+    float dist;
+    int geom;
+    int rec;
+};
+
 struct Counters {
-    unsigned long long rays, nodes, tris, planes;
+    unsigned rays, nodes, tris, planes; // per lane and launch (flushed into 64-bit device counters)
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
@@ -53,7 +63,7 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 
 // kernel.cu:138 — Ray(invM * vec4(o,1), normalize(invM * vec4(d,0))).  `len` is |invM*d| before normalisation: an
-// object-space parameter t corresponds to the world distance t / len (for a unit world direction).
+// object-space parameter t corresponds to the world distance t * |d_world| / len.
 __device__ __forceinline__ void object_space_ray(const GeomRecord& G, const Ray& r, Ray& o, float& len)
 {
     o.ox = (G.inv_c0[0] * r.ox + G.inv_c1[0] * r.oy) + (G.inv_c2[0] * r.oz + G.inv_c3[0]);
@@ -71,12 +81,10 @@ __device__ __forceinline__ void object_space_ray(const GeomRecord& G, const Ray&
     o.dz = tz * inv;
 }
 
-// kernel.cu:110-125 on a candidate at object-space parameter t.  Ties on the world distance resolve like the
-// reference's iteration order (lowest geometry index, then lowest triangle index), independent of the visiting order.
-// `scale` = len / |world direction| converts a world distance into this geometry's object-space t (pruning only).
+// kernel.cu:110-125 on a candidate at object-space parameter t (brute-force kernels).  Ties on the world distance
+// resolve like the reference's iteration order (lowest geometry index, then lowest triangle index).
 __device__ __forceinline__ void consider(const GeomRecord& G, int g, int rec, int orig_tri, float t, const Ray& osr, const Ray& wr,
-                                         float scale, const GeomRecord* __restrict__ geoms, const TriRecord* __restrict__ tris, Best& best,
-                                         float& tbound)
+                                         const GeomRecord* __restrict__ geoms, const TriRecord* __restrict__ tris, Best& best)
 {
     const float Px = osr.ox + osr.dx * t, Py = osr.oy + osr.dy * t, Pz = osr.oz + osr.dz * t; // kernel.cu:99 / :16
     const float wx = (G.mod_c0[0] * Px + G.mod_c1[0] * Py) + (G.mod_c2[0] * Pz + G.mod_c3[0]); // kernel.cu:113
@@ -100,22 +108,20 @@ __device__ __forceinline__ void consider(const GeomRecord& G, int g, int rec, in
         best.px = wx;
         best.py = wy;
         best.pz = wz;
-        tbound = (dist * 1.001f + 1.0e-3f) * scale; // conservative object-space bound for pruning only
     }
 }
 
 // kernel.cu:35-108 (Möller-Trumbore, division deferred, back faces culled).  Returns the object-space t or -1.
-__device__ __forceinline__ float triangle_t(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z, float v2x, float v2y,
-                                            float v2z, const Ray& r)
+__device__ __forceinline__ float triangle_t(const float4 A, const float4 B, const float4 C, const Ray& r)
 {
-    const float e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z; // :44
-    const float e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z; // :45
+    const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z; // :44
+    const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z; // :45
     const float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y; // :48 glm cross
     if (dot3(r.dx, r.dy, r.dz, nx, ny, nz) > 0.0f) return -1.0f;                                        // :49
     const float px = r.dy * e2z - e2y * r.dz, py = r.dz * e2x - e2z * r.dx, pz = r.dx * e2y - e2x * r.dy; // :53
     const float det = dot3(e1x, e1y, e1z, px, py, pz);                                                   // :54
     if (det < kTriEpsilon) return -1.0f;                                                                 // :57
-    const float tx = r.ox - v0x, ty = r.oy - v0y, tz = r.oz - v0z;                                       // :61
+    const float tx = r.ox - A.x, ty = r.oy - A.y, tz = r.oz - A.z;                                       // :61
     const float u = dot3(tx, ty, tz, px, py, pz);                                                        // :62
     if (u < 0.0f || u > det) return -1.0f;                                                               // :64
     const float qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;            // :68
@@ -127,15 +133,9 @@ __device__ __forceinline__ float triangle_t(float v0x, float v0y, float v0z, flo
     return t > kTriEpsilon ? t : -1.0f; // :97
 }
 
-__device__ __forceinline__ float triangle_t(const float4 a, const float4 b, const float4 c, const Ray& r)
+// kernel.cu:8-32 for an object-space ray and plane normal n.  Returns t or -1.
+__device__ __forceinline__ float plane_t(float nx, float ny, float nz, const Ray& r)
 {
-    return triangle_t(a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, r);
-}
-
-// kernel.cu:8-32.  Returns t or -1.
-__device__ __forceinline__ float plane_t(const GeomRecord& G, const Ray& r)
-{
-    const float nx = G.plane_n[0], ny = G.plane_n[1], nz = G.plane_n[2];
     const float denom = dot3(nx, ny, nz, r.dx, r.dy, r.dz); // :11
     if (!(fabsf(denom) >= kPlaneDenomMin)) return -1.0f;    // :12
     const float t = dot3(-r.ox, -r.oy, -r.oz, nx, ny, nz) / denom; // :14-15
@@ -160,6 +160,28 @@ struct Lds {
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
 };
+
+__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid)
+{
+    Lds L;
+    L.node_count = lds_nodes;
+    L.stride = block;
+    L.stack_base = lds_nodes * 16 + tid;
+    L.geom_base = lds_nodes * 4 + (stack_depth * block) / 4;
+    return L;
+}
+
+// Stage the top of the BVH and the geometry records: coalesced 16-byte loads, 1 KiB per wave-instruction.  Persistent
+// workgroups pay this once per launch, not per ray.
+__device__ __forceinline__ void stage_scene(const Lds& L, const BvhNode* __restrict__ nodes, const GeomRecord* __restrict__ geoms, int num_geoms,
+                                            int tid, int block)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(nodes);
+    for (int i = tid; i < L.node_count * 4; i += block) ff_smem[i] = src[i];
+    const uint4* gsrc = reinterpret_cast<const uint4*>(geoms);
+    for (int i = tid; i < num_geoms * kGeomVec4; i += block) ff_smem[L.geom_base + i] = gsrc[i];
+    __syncthreads();
+}
 
 __device__ __forceinline__ float4 lds_geom4(const Lds& L, int g, int k)
 {
@@ -188,31 +210,16 @@ __device__ __forceinline__ void fetch_node(const Lds& L, const BvhNode* __restri
     }
 }
 
-// Geometry record gathered by a lane-varying index from LDS (the uniform-index path reads the global copy through
-// scalar loads instead).
-struct GeomXf {
-    float i0x, i0y, i0z, z0, i1x, i1y, i1z, z1, i2x, i2y, i2z, z2, i3x, i3y, i3z; // inverse model columns + signed zeros
-    float m0x, m0y, m0z, m1x, m1y, m1z, m2x, m2y, m2z, m3x, m3y, m3z;             // model columns
-};
-
-__device__ __forceinline__ void load_inverse(const Lds& L, int g, GeomXf& X)
+// kernel.cu:138 with the geometry record gathered from LDS by a lane-varying index (same arithmetic as object_space_ray).
+__device__ __forceinline__ void object_space_ray_lds(const Lds& L, int g, const Ray& r, Ray& o, float& len)
 {
-    const float4 a = lds_geom4(L, g, 0), b = lds_geom4(L, g, 1), c = lds_geom4(L, g, 2), d = lds_geom4(L, g, 3);
-    X.i0x = a.x; X.i0y = a.y; X.i0z = a.z; X.z0 = a.w;
-    X.i1x = b.x; X.i1y = b.y; X.i1z = b.z; X.z1 = b.w;
-    X.i2x = c.x; X.i2y = c.y; X.i2z = c.z; X.z2 = c.w;
-    X.i3x = d.x; X.i3y = d.y; X.i3z = d.z;
-}
-
-// kernel.cu:138 with a lane-varying geometry (same arithmetic as object_space_ray).
-__device__ __forceinline__ void object_space_ray_x(const GeomXf& X, const Ray& r, Ray& o, float& len)
-{
-    o.ox = (X.i0x * r.ox + X.i1x * r.oy) + (X.i2x * r.oz + X.i3x);
-    o.oy = (X.i0y * r.ox + X.i1y * r.oy) + (X.i2y * r.oz + X.i3y);
-    o.oz = (X.i0z * r.ox + X.i1z * r.oy) + (X.i2z * r.oz + X.i3z);
-    const float tx = (X.i0x * r.dx + X.i1x * r.dy) + (X.i2x * r.dz + X.z0);
-    const float ty = (X.i0y * r.dx + X.i1y * r.dy) + (X.i2y * r.dz + X.z1);
-    const float tz = (X.i0z * r.dx + X.i1z * r.dy) + (X.i2z * r.dz + X.z2);
+    const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
+    o.ox = (c0.x * r.ox + c1.x * r.oy) + (c2.x * r.oz + c3.x);
+    o.oy = (c0.y * r.ox + c1.y * r.oy) + (c2.y * r.oz + c3.y);
+    o.oz = (c0.z * r.ox + c1.z * r.oy) + (c2.z * r.oz + c3.z);
+    const float tx = (c0.x * r.dx + c1.x * r.dy) + (c2.x * r.dz + c0.w);
+    const float ty = (c0.y * r.dx + c1.y * r.dy) + (c2.y * r.dz + c1.w);
+    const float tz = (c0.z * r.dx + c1.z * r.dy) + (c2.z * r.dz + c2.w);
     const float dd = (tx * tx + ty * ty) + tz * tz;
     len = sqrtf(dd);
     const float inv = 1.0f / len;
@@ -248,11 +255,11 @@ __device__ __forceinline__ WorldSlab make_world_slab(const Ray& wr)
 
 // Can the ray reach a world box before world distance `limit`?  Conservative: approximate arithmetic, inflated bounds,
 // padded boxes; a `false` only ever skips work that could not have produced the closest hit.
-__device__ __forceinline__ bool slab_may_hit(const float* wmin, const float* wmax, const WorldSlab& w, float limit)
+__device__ __forceinline__ bool slab_may_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const WorldSlab& w, float limit)
 {
-    const float a0 = __builtin_fmaf(wmin[0], w.ix, w.ox), a1 = __builtin_fmaf(wmax[0], w.ix, w.ox);
-    const float b0 = __builtin_fmaf(wmin[1], w.iy, w.oy), b1 = __builtin_fmaf(wmax[1], w.iy, w.oy);
-    const float c0 = __builtin_fmaf(wmin[2], w.iz, w.oz), c1 = __builtin_fmaf(wmax[2], w.iz, w.oz);
+    const float a0 = __builtin_fmaf(mnx, w.ix, w.ox), a1 = __builtin_fmaf(mxx, w.ix, w.ox);
+    const float b0 = __builtin_fmaf(mny, w.iy, w.oy), b1 = __builtin_fmaf(mxy, w.iy, w.oy);
+    const float c0 = __builtin_fmaf(mnz, w.iz, w.oz), c1 = __builtin_fmaf(mxz, w.iz, w.oz);
     const float bound = (limit * 1.001f + 1.0e-3f) * w.inv_len * 1.00001f;
     const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
     const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), bound));
@@ -274,9 +281,8 @@ __device__ __forceinline__ bool slab_may_hit(const float* wmin, const float* wma
 //   * The exact world distance (kernel.cu:113-114: IEEE divide, model transform, IEEE sqrt) is computed only when a
 //     pending candidate is resolved: once per ray in the common case, and immediately whenever two candidates are too
 //     close to rank approximately.  Ranking therefore always happens on exact reference distances.
-//   * BVH traversal alternates wave-wide between an inner-node phase and a leaf phase, so each phase runs with most
-//     lanes active instead of interleaving node visits and triangle tests lane by lane.
 
+constexpr int kLoopGuard = 1 << 16;              // upper bound on wave-level traversal rounds per query
 constexpr float kRel = 1.0e-4f, kAbs = 1.0e-4f; // screening margins, far above the rounding error of the fast forms
 
 struct Pending {
@@ -285,20 +291,35 @@ struct Pending {
     int rec;    // TriRecord index, -1 for a plane
 };
 
-// Resolve the pending candidate with the exact reference arithmetic (kernel.cu:35-125) and merge it into `best`.
-__device__ __forceinline__ void resolve_pending(const Lds& L, const GeomRecord* __restrict__ geoms, const TriRecord* __restrict__ tris,
-                                                const Ray& wr, Pending& pend, Best& best)
+// Per-lane state of one closest-hit query in flight.
+struct Segment {
+    BestId best;
+    Pending pend;
+    unsigned long long meshes; // candidate meshes not started yet (bit = record index)
+    int cur, sp, mesh;         // traversal cursor (inner >= 0, leaf < 0, kDone), stack height, record index of the current mesh
+    Ray osr;                   // object-space ray of the current mesh
+    float ix, iy, iz, ox, oy, oz; // 1/d and -o/d of osr (box tests)
+    float scale;               // object-space t per unit of world distance
+    int resume;                // > 0: triangle resume-1 of the leaf under the cursor met a near tie with the pending candidate;
+                               //      the caller resolves the pending one exactly, then the leaf continues from that triangle
+};
+
+__device__ __forceinline__ float inv_length(const Ray& r)
 {
-    const int g = pend.geom, rec = pend.rec;
-    pend.geom = -1;
-    pend.dist = kInf;
-    GeomXf X;
-    load_inverse(L, g, X);
+    return __builtin_amdgcn_rsqf(__builtin_fmaf(r.dx, r.dx, __builtin_fmaf(r.dy, r.dy, r.dz * r.dz)));
+}
+
+// Exact reference evaluation (kernel.cu:35-125) of candidate (g, rec) for world ray wr: world distance and hit point.
+// Returns false if the exact test rejects it (cannot happen for a screened candidate; kept so that a wrong margin
+// could never corrupt a result).
+__device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, int g, int rec, float& dist, float& wx,
+                                          float& wy, float& wz, int& orig_tri)
+{
     Ray osr;
     float len;
-    object_space_ray_x(X, wr, osr, len);
+    object_space_ray_lds(L, g, wr, osr, len);
     float t;
-    int orig_tri = -1;
+    orig_tri = -1;
     if (rec >= 0) {
         const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)rec * 3;
         const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -306,24 +327,31 @@ __device__ __forceinline__ void resolve_pending(const Lds& L, const GeomRecord* 
         t = triangle_t(a, b, c, osr);
     } else {
         const float4 pn = lds_geom4(L, g, 11);
-        // plane_t on gathered data (kernel.cu:8-32)
-        const float denom = dot3(pn.x, pn.y, pn.z, osr.dx, osr.dy, osr.dz);
-        t = -1.0f;
-        if (fabsf(denom) >= kPlaneDenomMin) {
-            const float tt = dot3(-osr.ox, -osr.oy, -osr.oz, pn.x, pn.y, pn.z) / denom;
-            const float Px = osr.ox + tt * osr.dx, Py = osr.oy + tt * osr.dy;
-            if (Px >= -0.5f && Px <= 0.5f && Py >= -0.5f && Py <= 0.5f && tt > 0.0f) t = tt;
-        }
+        t = plane_t(pn.x, pn.y, pn.z, osr);
     }
-    if (!(t > 0.0f)) return; // cannot happen for a screened candidate; kept so a wrong margin could not corrupt a result
+    if (!(t > 0.0f)) return false;
     const float4 m0 = lds_geom4(L, g, 4), m1 = lds_geom4(L, g, 5), m2 = lds_geom4(L, g, 6), m3 = lds_geom4(L, g, 7);
     const float Px = osr.ox + osr.dx * t, Py = osr.oy + osr.dy * t, Pz = osr.oz + osr.dz * t; // kernel.cu:99 / :16
-    const float wx = (m0.x * Px + m1.x * Py) + (m2.x * Pz + m3.x);                            // kernel.cu:113
-    const float wy = (m0.y * Px + m1.y * Py) + (m2.y * Pz + m3.y);
-    const float wz = (m0.z * Px + m1.z * Py) + (m2.z * Pz + m3.z);
+    wx = (m0.x * Px + m1.x * Py) + (m2.x * Pz + m3.x);                                        // kernel.cu:113
+    wy = (m0.y * Px + m1.y * Py) + (m2.y * Pz + m3.y);
+    wz = (m0.z * Px + m1.z * Py) + (m2.z * Pz + m3.z);
     const float vx = wr.ox - wx, vy = wr.oy - wy, vz = wr.oz - wz;
-    const float dist = sqrtf((vx * vx + vy * vy) + vz * vz); // kernel.cu:114
-    bool take = dist < best.dist;                             // kernel.cu:115
+    dist = sqrtf((vx * vx + vy * vy) + vz * vz); // kernel.cu:114
+    return true;
+}
+
+// Resolve the pending candidate exactly and merge it into `best` (kernel.cu:115-121).  Returns true if it became the
+// best; then (wx,wy,wz) is its hit point.
+__device__ __forceinline__ bool resolve_pending(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Pending& pend, BestId& best,
+                                                float& wx, float& wy, float& wz)
+{
+    const int g = pend.geom, rec = pend.rec;
+    pend.geom = -1;
+    pend.dist = kInf;
+    float dist;
+    int orig_tri;
+    if (!exact_hit(L, tris, wr, g, rec, dist, wx, wy, wz, orig_tri)) return false;
+    bool take = dist < best.dist; // kernel.cu:115
     if (!take && dist == best.dist && best.geom >= 0) {
         // the reference keeps the first hit in (geometry, triangle) iteration order among equal distances
         const int go = lds_geom_i4(L, g, 17).y, bo = lds_geom_i4(L, best.geom, 17).y;
@@ -334,74 +362,73 @@ __device__ __forceinline__ void resolve_pending(const Lds& L, const GeomRecord* 
         best.dist = dist;
         best.geom = g;
         best.rec = rec;
-        best.px = wx;
-        best.py = wy;
-        best.pz = wz;
     }
+    return take;
 }
 
-// Offer a certain hit at approximate world distance d to the lane's pending slot.
-__device__ __forceinline__ void offer(const Lds& L, const GeomRecord* __restrict__ geoms, const TriRecord* __restrict__ tris, const Ray& wr,
-                                      float d, int g, int rec, Pending& pend, Best& best)
+// Offer a certain hit at approximate world distance d to the lane's pending slot.  Returns true when the slot holds a
+// candidate that is too close to rank approximately: the caller must resolve the held one exactly (resolve_pending) and
+// offer this one again.  The exact code is kept OUT of the hot loops on purpose: it runs at wave-loop level, where the
+// loops' temporaries are dead, which keeps the kernel within the register budget of 4 waves per SIMD.
+__device__ __forceinline__ bool offer(float d, int g, int rec, Pending& pend, const BestId& best)
 {
     const float lim = fminf(best.dist, pend.dist);
-    if (d > lim * (1.0f + kRel) + kAbs) return;                       // clearly farther than something already held
-    if (pend.geom >= 0 && !(pend.dist > d * (1.0f + kRel) + kAbs))    // too close to rank approximately:
-        resolve_pending(L, geoms, tris, wr, pend, best);              //   settle the held one exactly first
+    if (d > lim * (1.0f + kRel) + kAbs) return false;                             // clearly farther than something already held
+    if (pend.geom >= 0 && !(pend.dist > d * (1.0f + kRel) + kAbs)) return true;   // near tie with the held candidate
     pend.dist = d;
     pend.geom = g;
     pend.rec = rec;
+    return false;
 }
 
+// Start a closest-hit query: screen all geometries, test the lane's candidate planes, remember its candidate meshes.
 template <bool STATS>
-__device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
-                                                     const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
-                                                     Best& best, Counters& cnt)
+__device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+                                              const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
-    best.dist = kInf; // kernel.cu:131
-    best.geom = -1;
-    best.rec = -1;
-    best.px = best.py = best.pz = 0.0f;
-    Pending pend = { kInf, -1, -1 };
+    S.best.dist = kInf; // kernel.cu:131
+    S.best.geom = -1;
+    S.best.rec = -1;
+    S.pend.dist = kInf;
+    S.pend.geom = -1;
+    S.pend.rec = -1;
+    S.cur = kDone;
+    S.sp = 0;
+    S.mesh = -1;
+    S.resume = 0;
     const WorldSlab ws = make_world_slab(wr);
 
-    // Geometries are handled in groups of 64 (one candidate bit per geometry); the reference's scenes have 5.
-    for (int gbase = 0; gbase < num_geoms; gbase += 64) {
-    const int gcount = min(64, num_geoms - gbase);
-
-    // 1. screen every geometry's world box (records are stored planes first, then meshes)
+    // 1. screen every geometry's world box: wave-uniform loop over the global records (scalar loads)
     unsigned long long cand = 0ull;
-    for (int j = 0; j < gcount; ++j) {
-        const GeomRecord& G = geoms[gbase + j];
-        if (slab_may_hit(G.wmin, G.wmax, ws, fminf(best.dist, pend.dist))) cand |= 1ull << j;
+    for (int g = 0; g < num_geoms; ++g) {
+        const GeomRecord& G = geoms[g];
+        if (slab_may_hit(G.wmin[0], G.wmin[1], G.wmin[2], G.wmax[0], G.wmax[1], G.wmax[2], ws, kInf)) cand |= 1ull << g;
     }
-    const int planes_here = max(0, min(64, num_planes - gbase));
-    const unsigned long long plane_bits = planes_here >= 64 ? ~0ull : ((1ull << planes_here) - 1ull);
+    const unsigned long long plane_bits = num_planes >= 64 ? ~0ull : ((1ull << num_planes) - 1ull);
+    S.meshes = cand & ~plane_bits;
 
-    // 2. planes: each lane walks its own candidates
+    // 2. planes: each lane walks its own candidates (records gathered from LDS); the loop is wave-wide so that the rare
+    //    exact resolution of a near tie sits at loop level
     unsigned long long pm = cand & plane_bits;
-    while (__ballot(pm != 0ull) != 0ull) {
+    for (int round = 0; round < 4 * 64 && __ballot(pm != 0ull) != 0ull; ++round) { // each plane takes at most two rounds
+        bool conflict = false;
         if (pm != 0ull) {
-            const int g = gbase + __ffsll((long long)pm) - 1;
-            pm &= pm - 1ull;
+            const int g = __ffsll((long long)pm) - 1;
+            bool hit = false;
+            float ta = 0.f, len = 1.f;
             const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-            const float wmin[3] = { bmin.x, bmin.y, bmin.z }, wmax[3] = { bmax.x, bmax.y, bmax.z };
-            if (slab_may_hit(wmin, wmax, ws, fminf(best.dist, pend.dist))) {
+            if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, fminf(S.best.dist, S.pend.dist))) {
                 if (STATS) cnt.planes += 1;
-                GeomXf X;
-                load_inverse(L, g, X);
                 Ray osr;
-                float len;
-                object_space_ray_x(X, wr, osr, len);
+                object_space_ray_lds(L, g, wr, osr, len);
                 const float4 pn = lds_geom4(L, g, 11);
-                const float denom = dot3(pn.x, pn.y, pn.z, osr.dx, osr.dy, osr.dz);     // kernel.cu:11 (exact)
-                if (fabsf(denom) >= kPlaneDenomMin) {                                    // kernel.cu:12 (exact)
-                    const float num = dot3(-osr.ox, -osr.oy, -osr.oz, pn.x, pn.y, pn.z); // kernel.cu:14-15 numerator (exact)
-                    float ta = num * __builtin_amdgcn_rcpf(denom);                       // approximate t
+                const float denom = dot3(pn.x, pn.y, pn.z, osr.dx, osr.dy, osr.dz);         // kernel.cu:11 (exact)
+                if (fabsf(denom) >= kPlaneDenomMin) {                                        // kernel.cu:12 (exact)
+                    const float num = dot3(-osr.ox, -osr.oy, -osr.oz, pn.x, pn.y, pn.z);     // kernel.cu:14-15 numerator (exact)
+                    ta = num * __builtin_amdgcn_rcpf(denom);                                 // approximate t
                     const float Pxa = __builtin_fmaf(ta, osr.dx, osr.ox), Pya = __builtin_fmaf(ta, osr.dy, osr.oy);
                     const float delta = 1.0e-5f * fmaxf(1.0f, fabsf(ta));
                     const float ex = fabsf(Pxa), ey = fabsf(Pya);
-                    bool hit = false;
                     if (ex <= 0.5f - delta && ey <= 0.5f - delta && ta > 1.0e-30f) {
                         hit = true; // clearly inside the quad and in front of the origin
                     } else if (ex <= 0.5f + delta && ey <= 0.5f + delta && ta > -1.0e-30f) {
@@ -411,130 +438,177 @@ __device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRec
                         hit = Px >= -0.5f && Px <= 0.5f && Py >= -0.5f && Py <= 0.5f && tt > 0.0f;
                         ta = tt;
                     }
-                    if (hit) offer(L, geoms, tris, wr, ta * __builtin_amdgcn_rcpf(len * ws.inv_len), g, -1, pend, best);
                 }
+            }
+            if (hit) conflict = offer(ta * __builtin_amdgcn_rcpf(len * ws.inv_len), g, -1, S.pend, S.best);
+            if (!conflict) pm &= pm - 1ull; // done with this plane (a conflicting one is offered again after the resolve)
+        }
+        if (__ballot(conflict) != 0ull) {
+            if (conflict) {
+                float x, y, z;
+                resolve_pending(L, tris, wr, S.pend, S.best, x, y, z);
             }
         }
     }
+}
 
-    // 3. meshes: lanes traverse the BVHs of their own candidate meshes; the wave alternates inner-node and leaf phases
-    unsigned long long mm = cand & ~plane_bits;
-    int cur = kDone, sp = 0, mg = -1;
-    Ray osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
-    float ix = 0.f, iy = 0.f, iz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f, scale = 1.f, wscale = 1.f;
-    for (;;) {
-        // (a) idle lanes start their next candidate mesh
-        while (__ballot(cur == kDone && mm != 0ull) != 0ull) {
-            if (cur == kDone && mm != 0ull) {
-                const int g = gbase + __ffsll((long long)mm) - 1;
-                mm &= mm - 1ull;
-                const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-                const float wmin[3] = { bmin.x, bmin.y, bmin.z }, wmax[3] = { bmax.x, bmax.y, bmax.z };
-                const int root = lds_geom_i4(L, g, 17).x;
-                if (root >= 0 && slab_may_hit(wmin, wmax, ws, fminf(best.dist, pend.dist))) {
-                    GeomXf X;
-                    load_inverse(L, g, X);
-                    float len;
-                    object_space_ray_x(X, wr, osr, len);
-                    ix = safe_rcp(osr.dx); iy = safe_rcp(osr.dy); iz = safe_rcp(osr.dz);
-                    ox = -osr.ox * ix; oy = -osr.oy * iy; oz = -osr.oz * iz;
-                    scale = len * ws.inv_len * 1.00001f;          // object-space t per unit of world distance
-                    wscale = __builtin_amdgcn_rcpf(len * ws.inv_len); // world distance per unit of object-space t
-                    mg = g;
-                    cur = root;
-                    sp = 0;
-                }
-            }
-        }
-        if (__ballot(cur != kDone) == 0ull) break;
+// Idle lane with candidate meshes left: enter the next one.
+__device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Segment& S)
+{
+    const int g = __ffsll((long long)S.meshes) - 1;
+    S.meshes &= S.meshes - 1ull;
+    const int root = lds_geom_i4(L, g, 17).x;
+    if (root < 0) return;
+    float len;
+    object_space_ray_lds(L, g, wr, S.osr, len);
+    S.ix = safe_rcp(S.osr.dx);
+    S.iy = safe_rcp(S.osr.dy);
+    S.iz = safe_rcp(S.osr.dz);
+    S.ox = -S.osr.ox * S.ix;
+    S.oy = -S.osr.oy * S.iy;
+    S.oz = -S.osr.oz * S.iz;
+    S.scale = len * inv_length(wr); // object-space t per unit of world distance
+    S.mesh = g;
+    S.cur = root;
+    S.sp = 0;
+}
 
-        // (b) inner-node phase: runs until no lane of the wave sits on an inner node
-        for (;;) {
-            const bool inner = cur >= 0 && cur != kDone;
-            if (__ballot(inner) == 0ull) break;
-            if (inner) {
-                uint4 q0, q1, q2, q3;
-                fetch_node(L, nodes, cur, q0, q1, q2, q3);
-                if (STATS) cnt.nodes += 1;
-                const float tbound = (fminf(best.dist, pend.dist) * 1.001f + 1.0e-3f) * scale;
-                // left box: q0.xyz = min, q1.xyz = max; right box: q2.xyz = min, q3.xyz = max (pruning only: FMA + approximate 1/d)
-                float a0 = __builtin_fmaf(__uint_as_float(q0.x), ix, ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), ix, ox);
-                float b0 = __builtin_fmaf(__uint_as_float(q0.y), iy, oy), b1 = __builtin_fmaf(__uint_as_float(q1.y), iy, oy);
-                float c0 = __builtin_fmaf(__uint_as_float(q0.z), iz, oz), c1 = __builtin_fmaf(__uint_as_float(q1.z), iz, oz);
-                const float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-                const float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
-                a0 = __builtin_fmaf(__uint_as_float(q2.x), ix, ox); a1 = __builtin_fmaf(__uint_as_float(q3.x), ix, ox);
-                b0 = __builtin_fmaf(__uint_as_float(q2.y), iy, oy); b1 = __builtin_fmaf(__uint_as_float(q3.y), iy, oy);
-                c0 = __builtin_fmaf(__uint_as_float(q2.z), iz, oz); c1 = __builtin_fmaf(__uint_as_float(q3.z), iz, oz);
-                const float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-                const float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
-                const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
-                const int left = (int)q0.w, right = (int)q1.w;
-                if (hl && hr) {
-                    const bool swap = rn < ln;
-                    stack_push(L, sp, swap ? left : right);
-                    ++sp;
-                    cur = swap ? right : left;
-                } else if (hl) {
-                    cur = left;
-                } else if (hr) {
-                    cur = right;
-                } else if (sp > 0) {
-                    --sp;
-                    cur = stack_pop(L, sp);
+// One inner-node visit: test both child boxes, descend to the nearer hit child, push the other, or pop.
+template <bool STATS>
+__device__ __forceinline__ void inner_step(const Lds& L, const BvhNode* __restrict__ nodes, Segment& S, Counters& cnt)
+{
+    uint4 q0, q1, q2, q3;
+    fetch_node(L, nodes, S.cur, q0, q1, q2, q3);
+    if (STATS) cnt.nodes += 1;
+    const float tbound = (fminf(S.best.dist, S.pend.dist) * 1.001f + 1.0e-3f) * S.scale * 1.00001f;
+    // left box: q0.xyz = min, q1.xyz = max; right box: q2.xyz = min, q3.xyz = max (pruning only: FMA + approximate 1/d)
+    float a0 = __builtin_fmaf(__uint_as_float(q0.x), S.ix, S.ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), S.ix, S.ox);
+    float b0 = __builtin_fmaf(__uint_as_float(q0.y), S.iy, S.oy), b1 = __builtin_fmaf(__uint_as_float(q1.y), S.iy, S.oy);
+    float c0 = __builtin_fmaf(__uint_as_float(q0.z), S.iz, S.oz), c1 = __builtin_fmaf(__uint_as_float(q1.z), S.iz, S.oz);
+    const float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+    const float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
+    a0 = __builtin_fmaf(__uint_as_float(q2.x), S.ix, S.ox); a1 = __builtin_fmaf(__uint_as_float(q3.x), S.ix, S.ox);
+    b0 = __builtin_fmaf(__uint_as_float(q2.y), S.iy, S.oy); b1 = __builtin_fmaf(__uint_as_float(q3.y), S.iy, S.oy);
+    c0 = __builtin_fmaf(__uint_as_float(q2.z), S.iz, S.oz); c1 = __builtin_fmaf(__uint_as_float(q3.z), S.iz, S.oz);
+    const float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+    const float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
+    const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
+    const int left = (int)q0.w, right = (int)q1.w;
+    if (hl && hr) {
+        const bool swap = rn < ln;
+        stack_push(L, S.sp, swap ? left : right);
+        ++S.sp;
+        S.cur = swap ? right : left;
+    } else if (hl) {
+        S.cur = left;
+    } else if (hr) {
+        S.cur = right;
+    } else if (S.sp > 0) {
+        --S.sp;
+        S.cur = stack_pop(L, S.sp);
+    } else {
+        S.cur = kDone;
+    }
+}
+
+// One leaf visit: test the leaf's triangles (fast form), then take the next entry off the stack.  On a near tie with the
+// pending candidate the leaf is left under the cursor with S.resume set; the caller resolves the pending candidate and
+// the leaf continues from the triangle that met the tie.
+template <bool STATS>
+__device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+{
+    const int ref = ~S.cur;
+    const int first = ref >> 3, count = (ref & 7) + 1;
+    const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)first * 3;
+    const Ray& r = S.osr;
+    int k = S.resume > 0 ? S.resume - 1 : 0;
+    S.resume = 0;
+    for (; k < count; ++k) {
+        const float4 A = tp[3 * k], B = tp[3 * k + 1], C = tp[3 * k + 2];
+        if (STATS) cnt.tris += 1;
+        // kernel.cu:44-75: exact up to the division; every accept/reject comparison is the reference's own
+        const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
+        const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
+        const float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
+        const float px = r.dy * e2z - e2y * r.dz, py = r.dz * e2x - e2z * r.dx, pz = r.dx * e2y - e2x * r.dy;
+        const float det = dot3(e1x, e1y, e1z, px, py, pz);
+        const float tx = r.ox - A.x, ty = r.oy - A.y, tz = r.oz - A.z;
+        const float u = dot3(tx, ty, tz, px, py, pz);
+        const float qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
+        const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz);
+        const float tn = dot3(e2x, e2y, e2z, qx, qy, qz);
+        bool ok = !(dot3(r.dx, r.dy, r.dz, nx, ny, nz) > 0.0f) && !(det < kTriEpsilon) && !(u < 0.0f || u > det) && !(v < 0.0f || u + v > det);
+        if (ok) {
+            float ta = tn * __builtin_amdgcn_rcpf(det); // approximate t (kernel.cu:77-79 is exact: 1/det, then multiply)
+            if (ta < kTriEpsilon * 1.001f) {
+                if (ta > kTriEpsilon * 0.999f) {
+                    ta = tn * (1.0f / det); // within the margin of the t > EPSILON test: decide exactly (kernel.cu:97)
+                    ok = ta > kTriEpsilon;
                 } else {
-                    cur = kDone;
+                    ok = false;
                 }
             }
-        }
-
-        // (c) leaf phase: every lane holding a leaf tests its triangles, then takes the next entry off its stack
-        if (cur < 0) {
-            const int ref = ~cur;
-            const int first = ref >> 3, count = (ref & 7) + 1;
-            const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)first * 3;
-            for (int k = 0; k < count; ++k) {
-                const float4 A = tp[3 * k], B = tp[3 * k + 1], C = tp[3 * k + 2];
-                if (STATS) cnt.tris += 1;
-                // kernel.cu:44-75: exact up to the division; every accept/reject comparison is the reference's own
-                const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
-                const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
-                const float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
-                const float px = osr.dy * e2z - e2y * osr.dz, py = osr.dz * e2x - e2z * osr.dx, pz = osr.dx * e2y - e2x * osr.dy;
-                const float det = dot3(e1x, e1y, e1z, px, py, pz);
-                const float tx = osr.ox - A.x, ty = osr.oy - A.y, tz = osr.oz - A.z;
-                const float u = dot3(tx, ty, tz, px, py, pz);
-                const float qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
-                const float v = dot3(osr.dx, osr.dy, osr.dz, qx, qy, qz);
-                const float tn = dot3(e2x, e2y, e2z, qx, qy, qz);
-                bool ok = !(dot3(osr.dx, osr.dy, osr.dz, nx, ny, nz) > 0.0f) && !(det < kTriEpsilon) && !(u < 0.0f || u > det) &&
-                          !(v < 0.0f || u + v > det);
-                if (ok) {
-                    float ta = tn * __builtin_amdgcn_rcpf(det); // approximate t (kernel.cu:77-79 is exact: 1/det, then multiply)
-                    if (ta < kTriEpsilon * 1.001f) {
-                        if (ta > kTriEpsilon * 0.999f) {
-                            ta = tn * (1.0f / det); // within the margin of the t > EPSILON test: decide exactly (kernel.cu:97)
-                            ok = ta > kTriEpsilon;
-                        } else {
-                            ok = false;
-                        }
-                    }
-                    if (ok) offer(L, geoms, tris, wr, ta * wscale, mg, first + k, pend, best);
-                }
-            }
-            if (sp > 0) {
-                --sp;
-                cur = stack_pop(L, sp);
-            } else {
-                cur = kDone;
+            if (ok && offer(ta * __builtin_amdgcn_rcpf(S.scale), S.mesh, first + k, S.pend, S.best)) {
+                S.resume = k + 1;
+                break;
             }
         }
     }
+    if (S.resume > 0) return;
+    if (S.sp > 0) {
+        --S.sp;
+        S.cur = stack_pop(L, S.sp);
+    } else {
+        S.cur = kDone;
+    }
+}
 
-    } // geometry groups
+// Settle what is still pending (the common case: the one exact evaluation of the ray, all hitting lanes together) and
+// produce the hit point of the winner.
+__device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Best& best)
+{
+    bool have_point = false;
+    best.px = best.py = best.pz = 0.0f;
+    if (S.pend.geom >= 0) have_point = resolve_pending(L, tris, wr, S.pend, S.best, best.px, best.py, best.pz);
+    if (!have_point && S.best.geom >= 0) {
+        // the winner was resolved earlier (two candidates had been too close to rank approximately): recompute its point
+        float dist;
+        int orig_tri;
+        exact_hit(L, tris, wr, S.best.geom, S.best.rec, dist, best.px, best.py, best.pz, orig_tri);
+    }
+    best.dist = S.best.dist;
+    best.geom = S.best.geom;
+    best.rec = S.best.rec;
+}
 
-    // 4. settle what is still pending (the common case: one exact evaluation per ray, all hitting lanes together)
-    if (pend.geom >= 0) resolve_pending(L, geoms, tris, wr, pend, best);
+// A complete closest-hit query for every calling lane (ray-batch kernel): the wave alternates mesh starts, inner-node
+// steps and leaf steps until all its lanes are done.
+template <bool STATS>
+__device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+                                                     const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
+                                                     Best& best, Counters& cnt)
+{
+    Segment S;
+    begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+    int guard = 0;
+    for (;;) {
+        while (S.cur == kDone && S.meshes != 0ull) start_next_mesh(L, wr, S);
+        if (__ballot(S.cur != kDone) == 0ull) break;
+        for (;;) {
+            const bool inner = S.cur >= 0 && S.cur != kDone;
+            if (__ballot(inner) == 0ull) break;
+            if (inner) inner_step<STATS>(L, nodes, S, cnt);
+        }
+        if (S.cur < 0) leaf_step<STATS>(L, tris, wr, S, cnt);
+        if (__ballot(S.resume > 0) != 0ull) {
+            if (S.resume > 0) {
+                float x, y, z;
+                resolve_pending(L, tris, wr, S.pend, S.best, x, y, z);
+            }
+        }
+        if (++guard > kLoopGuard) break; // never reached by a well-formed tree; bounds the loop so no wave can spin forever
+    }
+    finish_segment(L, tris, wr, S, best);
     cnt.rays += 1;
 }
 
@@ -555,7 +629,6 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
         float len;
         object_space_ray(G, wr, osr, len);
         if (G.type == FF_GEOM_TRIANGLEMESH) {
-            float tbound = kInf;
             for (int base = 0; base < G.tri_count; base += kBruteBatchTris) {
                 const int nb = min(kBruteBatchTris, G.tri_count - base);
                 __syncthreads();
@@ -566,48 +639,58 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
                     for (int k = 0; k < nb; ++k) {
                         const float4 a = batch[3 * k], b = batch[3 * k + 1], c = batch[3 * k + 2];
                         const float t = triangle_t(a, b, c, osr);
-                        if (t > 0.0f) consider(G, g, G.tri_first + base + k, __float_as_int(a.w), t, osr, wr, len, geoms, tris, best, tbound);
+                        if (t > 0.0f) consider(G, g, G.tri_first + base + k, __float_as_int(a.w), t, osr, wr, geoms, tris, best);
                     }
-                    if (STATS) cnt.tris += (unsigned long long)nb;
+                    if (STATS) cnt.tris += (unsigned)nb;
                 }
             }
         } else if (live) {
             if (STATS) cnt.planes += 1;
-            const float t = plane_t(G, osr);
-            float tb = kInf;
-            if (t > 0.0f) consider(G, g, -1, -1, t, osr, wr, len, geoms, tris, best, tb);
+            const float t = plane_t(G.plane_n[0], G.plane_n[1], G.plane_n[2], osr);
+            if (t > 0.0f) consider(G, g, -1, -1, t, osr, wr, geoms, tris, best);
         }
     }
     if (live) cnt.rays += 1;
 }
 
-// World-space normal of the closest hit: inverse(transpose(M)) * vec4(n_obj, 0)  (kernel.cu:117), with
-// n_obj = normalize(cross(e1, e2)) for triangles (kernel.cu:101) or the plane's m_normal (kernel.cu:26).
-__device__ __forceinline__ void world_normal(const GeomRecord& G, const TriRecord* __restrict__ tris, int rec, float& nx, float& ny, float& nz)
+// ---- shading --------------------------------------------------------------------------------------------------------
+
+// What shading needs from the hit geometry's record.
+struct Material {
+    float4 n0, n1, n2; // inverse-transpose columns (w = column3 * 0)
+    float4 plane_n, albedo, emission;
+    int bxdf_type;
+};
+
+__device__ __forceinline__ Material material_lds(const Lds& L, int g)
 {
-    float ox, oy, oz;
-    if (rec >= 0) {
-        const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)rec * 3;
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-        const float cx = e1y * e2z - e2y * e1z, cy = e1z * e2x - e2z * e1x, cz = e1x * e2y - e2x * e1y;
-        const float inv = 1.0f / sqrtf(dot3(cx, cy, cz, cx, cy, cz));
-        ox = cx * inv;
-        oy = cy * inv;
-        oz = cz * inv;
-    } else {
-        ox = G.plane_n[0];
-        oy = G.plane_n[1];
-        oz = G.plane_n[2];
-    }
-    nx = (G.nrm_c0[0] * ox + G.nrm_c1[0] * oy) + (G.nrm_c2[0] * oz + G.nrm_c0[3]);
-    ny = (G.nrm_c0[1] * ox + G.nrm_c1[1] * oy) + (G.nrm_c2[1] * oz + G.nrm_c1[3]);
-    nz = (G.nrm_c0[2] * ox + G.nrm_c1[2] * oy) + (G.nrm_c2[2] * oz + G.nrm_c2[3]);
+    Material m;
+    m.n0 = lds_geom4(L, g, 8);
+    m.n1 = lds_geom4(L, g, 9);
+    m.n2 = lds_geom4(L, g, 10);
+    m.plane_n = lds_geom4(L, g, 11);
+    m.albedo = lds_geom4(L, g, 12);
+    m.emission = lds_geom4(L, g, 13);
+    m.bxdf_type = lds_geom_i4(L, g, 16).y;
+    return m;
 }
 
-// world_normal with the geometry record gathered from LDS (BVH kernels)
-__device__ __forceinline__ void world_normal_lds(const Lds& L, int g, const TriRecord* __restrict__ tris, int rec, float& nx, float& ny, float& nz)
+__device__ __forceinline__ Material material_global(const GeomRecord& G)
+{
+    Material m;
+    m.n0 = make_float4(G.nrm_c0[0], G.nrm_c0[1], G.nrm_c0[2], G.nrm_c0[3]);
+    m.n1 = make_float4(G.nrm_c1[0], G.nrm_c1[1], G.nrm_c1[2], G.nrm_c1[3]);
+    m.n2 = make_float4(G.nrm_c2[0], G.nrm_c2[1], G.nrm_c2[2], G.nrm_c2[3]);
+    m.plane_n = make_float4(G.plane_n[0], G.plane_n[1], G.plane_n[2], 0.f);
+    m.albedo = make_float4(G.albedo[0], G.albedo[1], G.albedo[2], 0.f);
+    m.emission = make_float4(G.emission[0], G.emission[1], G.emission[2], 0.f);
+    m.bxdf_type = G.bxdf_type;
+    return m;
+}
+
+// World-space normal of the closest hit: inverse(transpose(M)) * vec4(n_obj, 0)  (kernel.cu:117), with
+// n_obj = normalize(cross(e1, e2)) for triangles (kernel.cu:101) or the plane's m_normal (kernel.cu:26).
+__device__ __forceinline__ void world_normal(const Material& M, const TriRecord* __restrict__ tris, int rec, float& nx, float& ny, float& nz)
 {
     float ox, oy, oz;
     if (rec >= 0) {
@@ -621,15 +704,13 @@ __device__ __forceinline__ void world_normal_lds(const Lds& L, int g, const TriR
         oy = cy * inv;
         oz = cz * inv;
     } else {
-        const float4 pn = lds_geom4(L, g, 11);
-        ox = pn.x;
-        oy = pn.y;
-        oz = pn.z;
+        ox = M.plane_n.x;
+        oy = M.plane_n.y;
+        oz = M.plane_n.z;
     }
-    const float4 n0 = lds_geom4(L, g, 8), n1 = lds_geom4(L, g, 9), n2 = lds_geom4(L, g, 10);
-    nx = (n0.x * ox + n1.x * oy) + (n2.x * oz + n0.w);
-    ny = (n0.y * ox + n1.y * oy) + (n2.y * oz + n1.w);
-    nz = (n0.z * ox + n1.z * oy) + (n2.z * oz + n2.w);
+    nx = (M.n0.x * ox + M.n1.x * oy) + (M.n2.x * oz + M.n0.w);
+    ny = (M.n0.y * ox + M.n1.y * oy) + (M.n2.y * oz + M.n1.w);
+    nz = (M.n0.z * ox + M.n1.z * oy) + (M.n2.z * oz + M.n2.w);
 }
 
 // ---- build-defined integrator pieces (DESIGN.md "Integrator"; mirrored by the oracle) ------------------------------
@@ -697,220 +778,184 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// ---- the mega-kernel ----------------------------------------------------------------------------------------------
+// Per-lane path state.
+struct Path {
+    int lpix;      // local pixel index (row-major in the local image)
+    unsigned gpix; // global pixel index y*W+x (kernel.cu:191), the RNG counter
+    int s, b;      // current sample / segment
+    Ray ray;       // current world-space ray
+    float bx, by, bz; // throughput
+    float ax, ay, az; // running sum over samples
+};
 
-template <int MODE, bool STATS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trace_kernel(const KParams p)
+// kernel.cu:197-205 for global pixel (x, y): origin = camera position, direction through the pixel corner.
+__device__ __forceinline__ void primary_ray(const KParams& p, unsigned gpix, Ray& ray)
 {
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
+    const int x = (int)(gpix % (unsigned)p.width), y = (int)(gpix / (unsigned)p.width);
+    const float Px = ((float)x / p.screen_w) * 2.f - 1.f;  // :200
+    const float Py = 1.f - ((float)y / p.screen_h) * 2.f;  // :201
+    const float v0 = Px * p.far_clip, v1 = Py * p.far_clip, v2 = 1.f * p.far_clip, v3 = 1.f * p.far_clip;
+    const float wx = (p.cam_c0[0] * v0 + p.cam_c1[0] * v1) + (p.cam_c2[0] * v2 + p.cam_c3[0] * v3); // :203
+    const float wy = (p.cam_c0[1] * v0 + p.cam_c1[1] * v1) + (p.cam_c2[1] * v2 + p.cam_c3[1] * v3);
+    const float wz = (p.cam_c0[2] * v0 + p.cam_c1[2] * v1) + (p.cam_c2[2] * v2 + p.cam_c3[2] * v3);
+    const float ddx = wx - p.cam_pos[0], ddy = wy - p.cam_pos[1], ddz = wz - p.cam_pos[2];
+    const float inv = 1.0f / sqrtf(dot3(ddx, ddy, ddz, ddx, ddy, ddz)); // :205
+    ray.ox = p.cam_pos[0];
+    ray.oy = p.cam_pos[1];
+    ray.oz = p.cam_pos[2];
+    ray.dx = ddx * inv;
+    ray.dy = ddy * inv;
+    ray.dz = ddz * inv;
+}
 
-    Lds L;
-    L.node_count = p.lds_nodes;
-    L.stride = BLOCK;
-    L.stack_base = p.lds_nodes * 16 + tid;
-    L.geom_base = p.lds_nodes * 4 + (p.stack_depth * BLOCK) / 4;
-    if (MODE == FF_TRACE_BVH) {
-        // Stage the top of the BVH and the geometry records once per workgroup: coalesced 16-byte loads, 1 KiB per
-        // wave-instruction.  The workgroup is persistent, so this is paid once per launch, not per ray.
-        const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
-        for (int i = tid; i < p.lds_nodes * 4; i += BLOCK) ff_smem[i] = src[i];
-        const uint4* gsrc = reinterpret_cast<const uint4*>(p.geoms);
-        for (int i = tid; i < p.num_geoms * kGeomVec4; i += BLOCK) ff_smem[L.geom_base + i] = gsrc[i];
-        __syncthreads();
-    }
-    float4* batch = reinterpret_cast<float4*>(ff_smem); // brute-force mode: triangle batch buffer
+__device__ __forceinline__ void start_sample(const KParams& p, Path& P)
+{
+    P.b = 0;
+    primary_ray(p, P.gpix, P.ray);
+    P.bx = P.by = P.bz = 1.f;
+}
 
-    Counters cnt = { 0, 0, 0, 0 };
-
-    // per-lane path state
-    bool active = false, exhausted = false;
-    int lpix = 0;          // local pixel index (row-major in the local image)
-    unsigned gpix = 0;     // global pixel index y*W+x (kernel.cu:191), the RNG counter
-    int s = 0, b = 0;      // current sample / segment
-    float pdx = 0.f, pdy = 0.f, pdz = 0.f; // primary direction of the pixel (no jitter: kernel.cu:200-205 uses the pixel corner)
-    Ray ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
-    float bx = 1.f, by = 1.f, bz = 1.f; // path throughput
-    float Lx = 0.f, Ly = 0.f, Lz = 0.f; // radiance of the current path
-    float ax = 0.f, ay = 0.f, az = 0.f; // running sum over samples
-    const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
-
+// Pull the next traceable pixel from the global queue for every calling lane (wave-wide ballot + prefix compaction
+// among the lanes that execute the call: one atomic per wave and round).  Returns false for lanes that saw the end of
+// the queue.
+__device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& P)
+{
+    bool got = false, exhausted = false;
     for (;;) {
-        // ---- refill: lanes without a pixel pull the next work items (wave-wide ballot + prefix compaction) ----
-        // Repeats until every lane of the wave either owns a traceable pixel or has seen the end of the queue (items that
-        // fall on tile padding or outside the traced region are consumed and skipped).
-        for (;;) {
-            const bool need = !active && !exhausted;
-            const unsigned long long need_mask = __ballot(need);
-            if (need_mask == 0ull) break;
-            unsigned base = 0;
-            const int leader = __ffsll((long long)need_mask) - 1;
-            if (lane == leader) base = atomicAdd(p.queue, (unsigned)__popcll(need_mask));
-            base = __shfl(base, leader);
-            if (need) {
-                const unsigned item = base + (unsigned)__popcll(need_mask & ((1ull << lane) - 1ull));
-                if (item >= p.total_items) {
-                    exhausted = true;
-                } else {
-                    const int tile = (int)(item >> 6), in = (int)(item & 63u);
-                    const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
-                    const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
-                    const int strip = ly / p.strip_rows;
-                    const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
-                    if (lx < p.xlim && ly < p.local_rows && gy < p.ylim) {
-                        active = true;
-                        lpix = ly * p.width + lx;
-                        gpix = (unsigned)(gy * p.width + lx);
-                        // kernel.cu:200-205
-                        const float Px = ((float)lx / p.screen_w) * 2.f - 1.f;
-                        const float Py = 1.f - ((float)gy / p.screen_h) * 2.f;
-                        const float v0 = Px * p.far_clip, v1 = Py * p.far_clip, v2 = 1.f * p.far_clip, v3 = 1.f * p.far_clip;
-                        const float wx = (p.cam_c0[0] * v0 + p.cam_c1[0] * v1) + (p.cam_c2[0] * v2 + p.cam_c3[0] * v3);
-                        const float wy = (p.cam_c0[1] * v0 + p.cam_c1[1] * v1) + (p.cam_c2[1] * v2 + p.cam_c3[1] * v3);
-                        const float wz = (p.cam_c0[2] * v0 + p.cam_c1[2] * v1) + (p.cam_c2[2] * v2 + p.cam_c3[2] * v3);
-                        const float ddx = wx - p.cam_pos[0], ddy = wy - p.cam_pos[1], ddz = wz - p.cam_pos[2];
-                        const float inv = 1.0f / sqrtf(dot3(ddx, ddy, ddz, ddx, ddy, ddz));
-                        pdx = ddx * inv;
-                        pdy = ddy * inv;
-                        pdz = ddz * inv;
-                        s = p.spp_begin;
-                        b = 0;
-                        ray.ox = p.cam_pos[0]; ray.oy = p.cam_pos[1]; ray.oz = p.cam_pos[2];
-                        ray.dx = pdx; ray.dy = pdy; ray.dz = pdz;
-                        bx = by = bz = 1.f;
-                        Lx = Ly = Lz = 0.f;
-                        if (p.first_chunk) {
-                            ax = ay = az = 0.f;
-                        } else {
-                            const float4 prev = reinterpret_cast<const float4*>(p.accum)[lpix];
-                            ax = prev.x; ay = prev.y; az = prev.z;
-                        }
-                    }
-                }
-            }
-        }
-        bool any_active;
-        if (MODE == FF_TRACE_BRUTE_FORCE) any_active = __syncthreads_or(active ? 1 : 0) != 0;
-        else any_active = __ballot(active) != 0ull;
-        if (!any_active) {
-            // In BVH mode a wave leaves once the queue is drained and all its lanes are done.  (A wave with some lanes
-            // waiting for work cannot get here: `need` lanes were refilled or marked exhausted above.)
-            break;
-        }
-
-        // ---- one path segment for every live lane ----
-        Best best;
-        if (MODE == FF_TRACE_BRUTE_FORCE) {
-            closest_hit_brute<STATS>(p.geoms, p.num_geoms, p.tris, batch, active, ray, best, cnt);
-        } else if (active) {
-            closest_hit_deferred<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, ray, best, cnt);
-        }
-        if (!active) continue;
-
-        bool path_done = true;
-        if (best.geom >= 0) {
-            float nx, ny, nz;
-            int bxdf_type;
-            float4 albedo, emission;
-            if (MODE == FF_TRACE_BVH) {
-                world_normal_lds(L, best.geom, p.tris, best.rec, nx, ny, nz);
-                bxdf_type = lds_geom_i4(L, best.geom, 16).y;
-                albedo = lds_geom4(L, best.geom, 12);
-                emission = lds_geom4(L, best.geom, 13);
+        const bool want = !got && !exhausted;
+        const unsigned long long m = __ballot(want);
+        if (m == 0ull) break;
+        unsigned base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(p.queue, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (want) {
+            const unsigned item = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (item >= p.total_items) {
+                exhausted = true;
             } else {
-                const GeomRecord& G = p.geoms[best.geom];
-                world_normal(G, p.tris, best.rec, nx, ny, nz);
-                bxdf_type = G.bxdf_type;
-                albedo = make_float4(G.albedo[0], G.albedo[1], G.albedo[2], 0.f);
-                emission = make_float4(G.emission[0], G.emission[1], G.emission[2], 0.f);
-            }
-            if (debug_shade) {
-                // shade(), kernel.cu:178-184
-                Lx = fabsf(nx); Ly = fabsf(ny); Lz = fabsf(nz);
-            } else if (bxdf_type == FF_BXDF_EMITTER) {
-                // utilities.h:96-103: two-sided emitter, m_emissiveColor * m_intensity
-                Lx = Lx + bx * emission.x;
-                Ly = Ly + by * emission.y;
-                Lz = Lz + bz * emission.z;
-            } else {
-                // everything else is diffuse (utilities.h:109); cosine-weighted sampling, so f*cos/pdf = albedo
-                bx = bx * albedo.x;
-                by = by * albedo.y;
-                bz = bz * albedo.z;
-                if (b != p.bounces - 1) {
-                    const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
-                    float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
-                    if (dot3(ux, uy, uz, ray.dx, ray.dy, ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; }
-                    unsigned r0, r1;
-                    philox2x32_10(gpix, ((unsigned)s << 8) | ((unsigned)b & 0xFFu), p.key, r0, r1);
-                    const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
-                    float wlx, wly, wlz;
-                    cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
-                    // orthonormal basis (Duff et al. 2017)
-                    const float sign = copysignf(1.0f, uz);
-                    const float aa = -1.0f / (sign + uz);
-                    const float bb = (ux * uy) * aa;
-                    const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
-                    const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
-                    const float wox = (t0 * wlx + s0 * wly) + ux * wlz;
-                    const float woy = (t1 * wlx + s1 * wly) + uy * wlz;
-                    const float woz = (t2 * wlx + s2 * wly) + uz * wlz;
-                    const float winv = 1.0f / sqrtf(dot3(wox, woy, woz, wox, woy, woz));
-                    ray.ox = best.px + ux * kRayEps;
-                    ray.oy = best.py + uy * kRayEps;
-                    ray.oz = best.pz + uz * kRayEps;
-                    ray.dx = wox * winv;
-                    ray.dy = woy * winv;
-                    ray.dz = woz * winv;
-                    ++b;
-                    path_done = false;
-                }
-            }
-        }
-        if (path_done) {
-            ax = ax + Lx;
-            ay = ay + Ly;
-            az = az + Lz;
-            ++s;
-            if (s >= p.spp_end || debug_shade) {
-                // pixel finished for this launch
-                if (p.last_chunk) {
-                    float rx, ry, rz;
-                    if (debug_shade) {
-                        rx = ax; ry = ay; rz = az;
+                // items walk 8x8 pixel tiles of the local image; padding items and untraced pixels are consumed and skipped
+                const int tile = (int)(item >> 6), in = (int)(item & 63u);
+                const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
+                const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
+                const int strip = ly / p.strip_rows;
+                const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
+                if (lx < p.xlim && ly < p.local_rows && gy < p.ylim) {
+                    got = true;
+                    P.lpix = ly * p.width + lx;
+                    P.gpix = (unsigned)(gy * p.width + lx);
+                    P.s = p.spp_begin;
+                    if (p.first_chunk) {
+                        P.ax = P.ay = P.az = 0.f;
                     } else {
-                        const float inv = 1.0f / (float)p.spp_total;
-                        rx = ax * inv; ry = ay * inv; rz = az * inv;
+                        const float4 prev = reinterpret_cast<const float4*>(p.accum)[P.lpix];
+                        P.ax = prev.x; P.ay = prev.y; P.az = prev.z;
                     }
-                    if (p.radiance) {
-                        p.radiance[3 * (size_t)lpix] = rx;
-                        p.radiance[3 * (size_t)lpix + 1] = ry;
-                        p.radiance[3 * (size_t)lpix + 2] = rz;
-                    }
-                    if (p.rgb8) {
-                        p.rgb8[3 * (size_t)lpix] = to_u8(rx);
-                        p.rgb8[3 * (size_t)lpix + 1] = to_u8(ry);
-                        p.rgb8[3 * (size_t)lpix + 2] = to_u8(rz);
-                    }
-                } else {
-                    reinterpret_cast<float4*>(p.accum)[lpix] = make_float4(ax, ay, az, 0.f);
+                    start_sample(p, P);
                 }
-                active = false;
-            } else {
-                b = 0;
-                ray.ox = p.cam_pos[0]; ray.oy = p.cam_pos[1]; ray.oz = p.cam_pos[2];
-                ray.dx = pdx; ray.dy = pdy; ray.dz = pdz;
-                bx = by = bz = 1.f;
-                Lx = Ly = Lz = 0.f;
             }
         }
     }
+    return got;
+}
 
+// Shade the finished segment and advance the path.  Returns true when the lane still owns its pixel (either the path
+// continues with a new ray in P.ray, or the next sample's primary ray was generated), false when the pixel is finished.
+__device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& best, bool hit, const Material& M, Path& P)
+{
+    const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
+    bool path_done = true;
+    // Radiance of the path: it is zero until the path ends on an emitter (the only light transport here), so it is not
+    // carried across segments; "0 + beta*Le" of the integrator is beta*Le bit for bit.
+    float Lx = 0.f, Ly = 0.f, Lz = 0.f;
+    if (hit) {
+        float nx, ny, nz;
+        world_normal(M, p.tris, best.rec, nx, ny, nz);
+        if (debug_shade) {
+            // shade(), kernel.cu:178-184
+            Lx = fabsf(nx); Ly = fabsf(ny); Lz = fabsf(nz);
+        } else if (M.bxdf_type == FF_BXDF_EMITTER) {
+            // utilities.h:96-103: two-sided emitter, m_emissiveColor * m_intensity
+            Lx = 0.f + P.bx * M.emission.x;
+            Ly = 0.f + P.by * M.emission.y;
+            Lz = 0.f + P.bz * M.emission.z;
+        } else {
+            // everything else is diffuse (utilities.h:109); cosine-weighted sampling, so f*cos/pdf = albedo
+            P.bx = P.bx * M.albedo.x;
+            P.by = P.by * M.albedo.y;
+            P.bz = P.bz * M.albedo.z;
+            if (P.b != p.bounces - 1) {
+                const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+                float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
+                if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; }
+                unsigned r0, r1;
+                philox2x32_10(P.gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
+                const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
+                float wlx, wly, wlz;
+                cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
+                // orthonormal basis (Duff et al. 2017)
+                const float sign = copysignf(1.0f, uz);
+                const float aa = -1.0f / (sign + uz);
+                const float bb = (ux * uy) * aa;
+                const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
+                const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
+                const float wox = (t0 * wlx + s0 * wly) + ux * wlz;
+                const float woy = (t1 * wlx + s1 * wly) + uy * wlz;
+                const float woz = (t2 * wlx + s2 * wly) + uz * wlz;
+                const float winv = 1.0f / sqrtf(dot3(wox, woy, woz, wox, woy, woz));
+                P.ray.ox = best.px + ux * kRayEps;
+                P.ray.oy = best.py + uy * kRayEps;
+                P.ray.oz = best.pz + uz * kRayEps;
+                P.ray.dx = wox * winv;
+                P.ray.dy = woy * winv;
+                P.ray.dz = woz * winv;
+                ++P.b;
+                path_done = false;
+            }
+        }
+    }
+    if (!path_done) return true;
+    P.ax = P.ax + Lx;
+    P.ay = P.ay + Ly;
+    P.az = P.az + Lz;
+    ++P.s;
+    if (P.s < p.spp_end && !debug_shade) {
+        start_sample(p, P);
+        return true;
+    }
+    // pixel finished for this launch
+    if (p.last_chunk) {
+        float rx, ry, rz;
+        if (debug_shade) {
+            rx = P.ax; ry = P.ay; rz = P.az;
+        } else {
+            const float inv = 1.0f / (float)p.spp_total;
+            rx = P.ax * inv; ry = P.ay * inv; rz = P.az * inv;
+        }
+        if (p.radiance) {
+            p.radiance[3 * (size_t)P.lpix] = rx;
+            p.radiance[3 * (size_t)P.lpix + 1] = ry;
+            p.radiance[3 * (size_t)P.lpix + 2] = rz;
+        }
+        if (p.rgb8) {
+            p.rgb8[3 * (size_t)P.lpix] = to_u8(rx);
+            p.rgb8[3 * (size_t)P.lpix + 1] = to_u8(ry);
+            p.rgb8[3 * (size_t)P.lpix + 2] = to_u8(rz);
+        }
+    } else {
+        reinterpret_cast<float4*>(p.accum)[P.lpix] = make_float4(P.ax, P.ay, P.az, 0.f);
+    }
+    return false;
+}
+
+__device__ __forceinline__ void flush_counters(const KParams& p, int lane, const Counters& cnt, bool stats)
+{
     // wave-reduced counters, one atomic per wave and counter
-    const unsigned long long rays = wave_sum(cnt.rays);
+    const unsigned long long rays = wave_sum((unsigned long long)cnt.rays);
     if (lane == 0 && rays) atomicAdd(&p.counters[0], rays);
-    if (STATS) {
-        const unsigned long long n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), pl = wave_sum(cnt.planes);
+    if (stats) {
+        const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
+                                 pl = wave_sum((unsigned long long)cnt.planes);
         if (lane == 0) {
             if (n) atomicAdd(&p.counters[1], n);
             if (t) atomicAdd(&p.counters[2], t);
@@ -919,23 +964,90 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(const KParams p)
     }
 }
 
+__device__ __forceinline__ void init_path(Path& P)
+{
+    P.lpix = 0; P.gpix = 0; P.s = 0; P.b = 0;
+    P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    P.bx = P.by = P.bz = 1.f;
+    P.ax = P.ay = P.az = 0.f;
+}
+
+// ---- the BVH mega-kernel -------------------------------------------------------------------------------------------------
+//
+// Segment-synchronous: in every round each live lane of the wave runs one complete closest-hit query and then
+// resolves/shades/spawns together with its neighbours.  (A per-lane state machine that let finished lanes wait for a
+// quorum while others kept traversing was measured slower on MI355X: the setup block is too large to run at partial
+// occupancy, see DESIGN.md.)  Latency is hidden by occupancy: 1024 threads per workgroup = 4 waves per SIMD.
+
+template <bool STATS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
+    stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
+
+    Counters cnt = { 0, 0, 0, 0 };
+    Path P;
+    init_path(P);
+    bool active = false, exhausted = false;
+    for (;;) {
+        if (!active && !exhausted) {
+            active = acquire_pixel(p, lane, P);
+            exhausted = !active;
+        }
+        if (__ballot(active) == 0ull) break;
+        if (active) {
+            Best best;
+            closest_hit_deferred<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, P.ray, best, cnt);
+            const bool hit = best.geom >= 0;
+            Material M;
+            if (hit) M = material_lds(L, best.geom);
+            else M.bxdf_type = FF_BXDF_COUNT;
+            active = shade_and_advance(p, best, hit, M, P);
+        }
+    }
+    flush_counters(p, lane, cnt, STATS);
+}
+
+// ---- the brute-force mega-kernel (reference loop, validation path) ---------------------------------------------------
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParams p)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
+    Counters cnt = { 0, 0, 0, 0 };
+    Path P;
+    init_path(P);
+    bool active = false, exhausted = false;
+    for (;;) {
+        if (!active && !exhausted) {
+            active = acquire_pixel(p, lane, P);
+            exhausted = !active;
+        }
+        // every thread of the workgroup takes part in staging the triangle batches
+        if (__syncthreads_or(active ? 1 : 0) == 0) break;
+        Best best;
+        closest_hit_brute<STATS>(p.geoms, p.num_geoms, p.tris, batch, active, P.ray, best, cnt);
+        if (!active) continue;
+        const bool hit = best.geom >= 0;
+        Material M;
+        if (hit) M = material_global(p.geoms[best.geom]);
+        else M.bxdf_type = FF_BXDF_COUNT;
+        active = shade_and_advance(p, best, hit, M, P);
+    }
+    flush_counters(p, lane, cnt, STATS);
+}
+
 // Batch closest-hit query: intersectRays (kernel.cu:127-176) for caller-supplied rays, one thread per ray.
 template <int MODE>
 __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatchParams p)
 {
     const int tid = threadIdx.x;
-    Lds L;
-    L.node_count = p.lds_nodes;
-    L.stride = kBlockThreads;
-    L.stack_base = p.lds_nodes * 16 + tid;
-    L.geom_base = p.lds_nodes * 4 + (p.stack_depth * kBlockThreads) / 4;
-    if (MODE == FF_TRACE_BVH) {
-        const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
-        for (int i = tid; i < p.lds_nodes * 4; i += kBlockThreads) ff_smem[i] = src[i];
-        const uint4* gsrc = reinterpret_cast<const uint4*>(p.geoms);
-        for (int i = tid; i < p.num_geoms * kGeomVec4; i += kBlockThreads) ff_smem[L.geom_base + i] = gsrc[i];
-        __syncthreads();
-    }
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, kBlockThreads, tid);
+    if (MODE == FF_TRACE_BVH) stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);
     const int i = blockIdx.x * kBlockThreads + tid;
     const bool live = i < p.n;
@@ -961,8 +1073,9 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     out.triangleIndex = -1; // :65
     if (best.geom >= 0) {
         const GeomRecord& G = p.geoms[best.geom];
+        const Material M = material_global(G);
         float nx, ny, nz;
-        world_normal(G, p.tris, best.rec, nx, ny, nz);
+        world_normal(M, p.tris, best.rec, nx, ny, nz);
         out.m_intersectionPoint.x = best.px; out.m_intersectionPoint.y = best.py; out.m_intersectionPoint.z = best.pz;
         out.m_normal.x = nx; out.m_normal.y = ny; out.m_normal.z = nz;
         out.m_t = best.dist;   // kernel.cu:119: the world distance
@@ -1019,12 +1132,14 @@ hipError_t prepare_kernels()
 #define FF_SET_LDS(K)                                                                                                     \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudgetBytes); \
     if (e != hipSuccess) return e;
-    // Only the BVH kernels go past the 64 KiB default (node cache + stacks); the brute-force kernels use a 48 KiB batch
-    // buffer plus a little static LDS, and asking for the full 160 KiB on top of static LDS is rejected.
-    FF_SET_LDS((trace_kernel<FF_TRACE_BVH, false, 512>))
-    FF_SET_LDS((trace_kernel<FF_TRACE_BVH, true, 512>))
-    FF_SET_LDS((trace_kernel<FF_TRACE_BVH, false, 1024>))
-    FF_SET_LDS((trace_kernel<FF_TRACE_BVH, true, 1024>))
+    // Only the BVH kernels go past the 64 KiB default (node cache + stacks + geometry records); the brute-force kernels
+    // use a 48 KiB batch buffer plus a little static LDS, and asking for 160 KiB on top of static LDS is rejected.
+    FF_SET_LDS((trace_bvh_kernel<false, 512>))
+    FF_SET_LDS((trace_bvh_kernel<true, 512>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768>))
+    FF_SET_LDS((trace_bvh_kernel<true, 768>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024>))
+    FF_SET_LDS((trace_bvh_kernel<true, 1024>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
 #undef FF_SET_LDS
     return hipSuccess;
@@ -1032,20 +1147,25 @@ hipError_t prepare_kernels()
 
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream)
 {
-    const dim3 grid(grid_blocks), block(block_threads);
+    const dim3 grid(grid_blocks);
     if (trace_mode == FF_TRACE_BVH) {
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
+        const dim3 block(block_threads);
         if (block_threads == 1024) {
-            if (collect_stats) hipLaunchKernelGGL((trace_kernel<FF_TRACE_BVH, true, 1024>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((trace_kernel<FF_TRACE_BVH, false, 1024>), grid, block, lds, stream, p);
+            if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 1024>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((trace_bvh_kernel<false, 1024>), grid, block, lds, stream, p);
+        } else if (block_threads == 768) {
+            if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 768>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((trace_bvh_kernel<false, 768>), grid, block, lds, stream, p);
         } else {
-            if (collect_stats) hipLaunchKernelGGL((trace_kernel<FF_TRACE_BVH, true, 512>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((trace_kernel<FF_TRACE_BVH, false, 512>), grid, block, lds, stream, p);
+            if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 512>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((trace_bvh_kernel<false, 512>), grid, block, lds, stream, p);
         }
     } else {
         const size_t lds = (size_t)kBruteBatchTris * sizeof(TriRecord);
-        if (collect_stats) hipLaunchKernelGGL((trace_kernel<FF_TRACE_BRUTE_FORCE, true, 512>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((trace_kernel<FF_TRACE_BRUTE_FORCE, false, 512>), grid, block, lds, stream, p);
+        const dim3 block(kBlockThreads);
+        if (collect_stats) hipLaunchKernelGGL((trace_brute_kernel<true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((trace_brute_kernel<false>), grid, block, lds, stream, p);
     }
     return hipGetLastError();
 }
@@ -1053,7 +1173,8 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream)
 {
     if (p.n <= 0) return hipSuccess;
-    const size_t lds = trace_mode == FF_TRACE_BVH ? bvh_lds_bytes(p.lds_nodes, p.stack_depth, kBlockThreads, p.num_geoms) : (size_t)kBruteBatchTris * sizeof(TriRecord);
+    const size_t lds = trace_mode == FF_TRACE_BVH ? bvh_lds_bytes(p.lds_nodes, p.stack_depth, kBlockThreads, p.num_geoms)
+                                                  : (size_t)kBruteBatchTris * sizeof(TriRecord);
     const dim3 grid((p.n + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
     if (trace_mode == FF_TRACE_BVH) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BRUTE_FORCE>), grid, block, lds, stream, p);
