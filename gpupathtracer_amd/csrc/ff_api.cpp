@@ -40,8 +40,10 @@ struct FfState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
-    int setup_threshold = 24, leaf_threshold = 16; // BVH kernel scheduling knobs (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
+    int setup_threshold = 12, leaf_threshold = 64; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
+                                                   // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
+    unsigned long long raw_counters[16] = {};
     // GL interop
     hipGraphicsResource* pbo_resource = nullptr;
     int pbo_width = 0, pbo_height = 0;
@@ -176,7 +178,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced and missed pixels read 0
     if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
     if (radiance_dev) FF_HIP(hipMemsetAsync(radiance_dev, 0, local_pixels * 3 * sizeof(float), st));
-    FF_HIP(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), st));
+    FF_HIP(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), st));
     FF_HIP(hipEventRecord(s->ev_begin, st));
     for (int l = 0; l < launches; ++l) {
         k.spp_begin = l * chunk;
@@ -190,8 +192,9 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     FF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     FF_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
-    unsigned long long c[8];
+    unsigned long long c[16];
     FF_HIP(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    std::memcpy(s->raw_counters, c, sizeof c);
     s->stats.rays_traced = c[0];
     s->stats.nodes_visited = c[1];
     s->stats.tris_tested = c[2];
@@ -227,14 +230,14 @@ int ff_create(FfState** out_state, int device_id)
         const int v = std::atoi(bt);
         if (v == 512 || v == 768 || v == 1024) s->block_threads = v;
     }
-    if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) s->setup_threshold = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) s->setup_threshold = std::max(0, std::min(1 << 14, std::atoi(e)));
     if (const char* e = std::getenv("FF_LEAF_THRESHOLD")) s->leaf_threshold = std::max(1, std::min(64, std::atoi(e)));
     hipError_t pe = prepare_kernels();
     if (pe != hipSuccess) {
         delete s;
         return fail(FF_ERR_HIP, "ff_create: kernel preparation failed: %s (is this a gfx950 device?)", hipGetErrorString(pe));
     }
-    if (hipMalloc((void**)&s->d_queue, 64) != hipSuccess || hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&s->d_queue, 64) != hipSuccess || hipMalloc((void**)&s->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         ff_destroy(s);
         return fail(FF_ERR_HIP, "ff_create: allocating work buffers failed");
@@ -487,6 +490,14 @@ int ff_set_collect_stats(FfState* s, int on)
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_set_collect_stats: state is null");
     s->collect_stats = on != 0;
+    return FF_OK;
+}
+
+int ff_debug_counters(FfState* s, unsigned long long* out16)
+{
+    clear_error();
+    if (!s || !out16) return fail(FF_ERR_INVALID_ARG, "ff_debug_counters: null argument");
+    std::memcpy(out16, s->raw_counters, sizeof s->raw_counters);
     return FF_OK;
 }
 

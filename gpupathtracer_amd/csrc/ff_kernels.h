@@ -31,8 +31,8 @@ struct KParams {
     unsigned key;       // Philox key (seed folded to 32 bits)
     int shade_mode;
     int first_chunk, last_chunk;
-    // BVH kernel scheduling knobs: lanes waiting for setup run it together once this many have gathered; a leaf step runs
-    // once this many lanes hold a leaf (both also run as soon as nothing else can make progress)
+    // BVH kernel scheduling knobs: setup_threshold = traversal time slice in inner-node rounds (0 = run every query to
+    // completion before the wave shades); leaf_threshold = number of lanes holding a leaf that ends an inner-node phase early
     int setup_threshold, leaf_threshold;
     // scene
     int num_geoms;

@@ -53,7 +53,17 @@ struct BestId {
 
 struct Counters {
     unsigned rays, nodes, tris, planes; // per lane and launch (flushed into 64-bit device counters)
+    // occupancy probes (instrumented launches only): wave-level rounds of each phase.  The active-lane totals of the
+    // phases are the counters above (nodes = inner-step lanes, tris = triangle-test lanes, planes, rays).
+    unsigned inner_rounds, leaf_rounds, tri_rounds, plane_rounds, segment_rounds;
 };
+
+// Count one wave-level round of a phase: exactly one of the active lanes (the lowest) records it.
+__device__ __forceinline__ void probe_round(unsigned& counter)
+{
+    const unsigned long long m = __ballot(true);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) counter += 1;
+}
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
@@ -413,6 +423,7 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     for (int round = 0; round < 4 * 64 && __ballot(pm != 0ull) != 0ull; ++round) { // each plane takes at most two rounds
         bool conflict = false;
         if (pm != 0ull) {
+            if (STATS) probe_round(cnt.plane_rounds);
             const int g = __ffsll((long long)pm) - 1;
             bool hit = false;
             float ta = 0.f, len = 1.f;
@@ -479,7 +490,7 @@ __device__ __forceinline__ void inner_step(const Lds& L, const BvhNode* __restri
 {
     uint4 q0, q1, q2, q3;
     fetch_node(L, nodes, S.cur, q0, q1, q2, q3);
-    if (STATS) cnt.nodes += 1;
+    if (STATS) { cnt.nodes += 1; probe_round(cnt.inner_rounds); }
     const float tbound = (fminf(S.best.dist, S.pend.dist) * 1.001f + 1.0e-3f) * S.scale * 1.00001f;
     // left box: q0.xyz = min, q1.xyz = max; right box: q2.xyz = min, q3.xyz = max (pruning only: FMA + approximate 1/d)
     float a0 = __builtin_fmaf(__uint_as_float(q0.x), S.ix, S.ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), S.ix, S.ox);
@@ -523,9 +534,10 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
     const Ray& r = S.osr;
     int k = S.resume > 0 ? S.resume - 1 : 0;
     S.resume = 0;
+    if (STATS) probe_round(cnt.leaf_rounds);
     for (; k < count; ++k) {
         const float4 A = tp[3 * k], B = tp[3 * k + 1], C = tp[3 * k + 2];
-        if (STATS) cnt.tris += 1;
+        if (STATS) { cnt.tris += 1; probe_round(cnt.tri_rounds); }
         // kernel.cu:44-75: exact up to the division; every accept/reject comparison is the reference's own
         const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
         const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
@@ -581,22 +593,27 @@ __device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __
     best.rec = S.best.rec;
 }
 
-// A complete closest-hit query for every calling lane (ray-batch kernel): the wave alternates mesh starts, inner-node
-// steps and leaf steps until all its lanes are done.
+__device__ __forceinline__ bool segment_done(const Segment& S) { return S.cur == kDone && S.meshes == 0ull && S.resume == 0; }
+
+// Advance the queries of the calling lanes: mesh starts, inner-node phases, leaf phases and near-tie resolutions alternate
+// wave-wide until every calling lane is done or `budget` inner-node rounds have been spent (budget <= 0: no limit).
+// Unfinished lanes keep their state in S and continue on the next call.
 template <bool STATS>
-__device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
-                                                     const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
-                                                     Best& best, Counters& cnt)
+__device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
+                                                Segment& S, Counters& cnt, int budget, int leaf_threshold)
 {
-    Segment S;
-    begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
-    int guard = 0;
+    const int limit = budget > 0 ? budget : kLoopGuard;
+    int rounds = 0, guard = 0;
     for (;;) {
         while (S.cur == kDone && S.meshes != 0ull) start_next_mesh(L, wr, S);
         if (__ballot(S.cur != kDone) == 0ull) break;
         for (;;) {
             const bool inner = S.cur >= 0 && S.cur != kDone;
             if (__ballot(inner) == 0ull) break;
+            // enough lanes hold a leaf: test the leaves now instead of idling them until the last lane finds one
+            if (__popcll(__ballot(S.cur < 0)) >= leaf_threshold) break;
+            if (rounds >= limit) break;
+            ++rounds;
             if (inner) inner_step<STATS>(L, nodes, S, cnt);
         }
         if (S.cur < 0) leaf_step<STATS>(L, tris, wr, S, cnt);
@@ -606,8 +623,21 @@ __device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRec
                 resolve_pending(L, tris, wr, S.pend, S.best, x, y, z);
             }
         }
+        if (rounds >= limit) break;
         if (++guard > kLoopGuard) break; // never reached by a well-formed tree; bounds the loop so no wave can spin forever
     }
+}
+
+// A complete closest-hit query for every calling lane (ray-batch kernel).
+template <bool STATS>
+__device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+                                                     const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
+                                                     Best& best, Counters& cnt)
+{
+    Segment S;
+    if (STATS) probe_round(cnt.segment_rounds);
+    begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+    traverse_budget<STATS>(L, tris, nodes, wr, S, cnt, 0, 64);
     finish_segment(L, tris, wr, S, best);
     cnt.rays += 1;
 }
@@ -956,10 +986,18 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
     if (stats) {
         const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
                                  pl = wave_sum((unsigned long long)cnt.planes);
+        const unsigned long long r0 = wave_sum((unsigned long long)cnt.inner_rounds), r1 = wave_sum((unsigned long long)cnt.leaf_rounds),
+                                 r2 = wave_sum((unsigned long long)cnt.tri_rounds), r3 = wave_sum((unsigned long long)cnt.plane_rounds),
+                                 r4 = wave_sum((unsigned long long)cnt.segment_rounds);
         if (lane == 0) {
             if (n) atomicAdd(&p.counters[1], n);
             if (t) atomicAdd(&p.counters[2], t);
             if (pl) atomicAdd(&p.counters[3], pl);
+            atomicAdd(&p.counters[8], r0);
+            atomicAdd(&p.counters[9], r1);
+            atomicAdd(&p.counters[10], r2);
+            atomicAdd(&p.counters[11], r3);
+            atomicAdd(&p.counters[12], r4);
         }
     }
 }
@@ -987,25 +1025,46 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
-    Counters cnt = { 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
-    bool active = false, exhausted = false;
+    Segment S;
+    S.best = { kInf, -1, -1 };
+    S.pend = { kInf, -1, -1 };
+    S.meshes = 0ull;
+    S.cur = kDone; S.sp = 0; S.mesh = -1; S.resume = 0;
+    S.osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
+    S.scale = 1.f;
+    bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
     for (;;) {
-        if (!active && !exhausted) {
-            active = acquire_pixel(p, lane, P);
-            exhausted = !active;
+        // Lanes whose query is finished (or that have none) resolve + shade + spawn together; lanes still traversing skip.
+        if (!inflight || segment_done(S)) {
+            if (inflight) {
+                Best best;
+                finish_segment(L, p.tris, P.ray, S, best);
+                const bool hit = best.geom >= 0;
+                Material M;
+                if (hit) M = material_lds(L, best.geom);
+                else M.bxdf_type = FF_BXDF_COUNT;
+                active = shade_and_advance(p, best, hit, M, P);
+                inflight = false;
+            }
+            if (!active && !exhausted) {
+                active = acquire_pixel(p, lane, P);
+                exhausted = !active;
+            }
+            if (active) {
+                if (STATS) probe_round(cnt.segment_rounds);
+                begin_segment<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
+                cnt.rays += 1;
+                inflight = true;
+            }
         }
-        if (__ballot(active) == 0ull) break;
-        if (active) {
-            Best best;
-            closest_hit_deferred<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, P.ray, best, cnt);
-            const bool hit = best.geom >= 0;
-            Material M;
-            if (hit) M = material_lds(L, best.geom);
-            else M.bxdf_type = FF_BXDF_COUNT;
-            active = shade_and_advance(p, best, hit, M, P);
-        }
+        if (__ballot(inflight) == 0ull) break;
+        // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
+        // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
+        if (inflight) traverse_budget<STATS>(L, p.tris, p.nodes, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold);
     }
     flush_counters(p, lane, cnt, STATS);
 }
@@ -1018,7 +1077,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
-    Counters cnt = { 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     bool active = false, exhausted = false;
@@ -1059,7 +1118,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     }
     Best best;
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f;
-    Counters cnt = { 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
     if (!live) return;

@@ -19,7 +19,7 @@ EXPORTS = [
     "ff_geometry_init", "ff_bxdf_init", "ff_camera_init_default", "ff_camera_update_basis", "ff_camera_ray_matrix",
     "ff_upload_scene", "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
-    "ff_set_collect_stats", "ff_stats", "ff_load_obj", "ff_free_triangles",
+    "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_load_obj", "ff_free_triangles",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load():
     lib.ff_render_to_pbo.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams)]
     lib.ff_set_collect_stats.argtypes = [vp, i32]
     lib.ff_stats.argtypes = [vp, P(T.FfStats)]
+    lib.ff_debug_counters.argtypes = [vp, P(C.c_ulonglong)]
     lib.ff_load_obj.argtypes = [C.c_char_p, P(P(T.FfTriangle)), P(i32)]
     lib.ff_free_triangles.argtypes = [P(T.FfTriangle)]
     lib.ff_free_triangles.restype = None
@@ -148,6 +149,11 @@ class Tracer:
         st = T.FfStats()
         check(self._lib.ff_stats(self._state, C.byref(st)))
         return st
+
+    def debug_counters(self):
+        buf = (C.c_ulonglong * 16)()
+        check(self._lib.ff_debug_counters(self._state, buf))
+        return list(buf)
 
     def render(self, camera, params, want_rgb8=True, want_radiance=True):
         """Headless frame to host numpy arrays: (rgb8 [H,W,3] uint8, radiance [H,W,3] float32)."""

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Print the SIMD occupancy of each phase of the BVH kernel on the C2 workload (instrumented launch)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpupathtracer_amd import lib, scenes, types as T
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+scene = scenes.cornell_wahoo_scene()
+cam = scenes.posed_camera(1920, 1080, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+with lib.Tracer(0) as t:
+    t.upload_scene(scene)
+    t.set_collect_stats(True)
+    t.render(cam, lib.render_params(1920, 1080, 8, spp), want_rgb8=False, want_radiance=False)
+    c = t.debug_counters()
+    st = t.stats()
+rays, nodes, tris, planes = c[0], c[1], c[2], c[3]
+ir, lr, tr, pr, sr = c[8], c[9], c[10], c[11], c[12]
+budget = os.environ.get("FF_SETUP_THRESHOLD")
+print(f"budget {budget} rays {rays}  kernel_ms {st.kernel_ms:.1f}  Mrays/s {rays / st.kernel_ms / 1e3:.0f}")
+print(f"segments: rounds {sr}  occupancy {rays / (64 * sr):.3f}")
+print(f"planes  : per ray {planes / rays:.2f}  rounds/segment-round {pr / sr:.2f}  occupancy {planes / (64 * pr):.3f}")
+print(f"inner   : per ray {nodes / rays:.2f}  rounds/segment-round {ir / sr:.2f}  occupancy {nodes / (64 * ir):.3f}")
+print(f"leaves  : rounds/segment-round {lr / sr:.2f}")
+print(f"tris    : per ray {tris / rays:.2f}  rounds/segment-round {tr / sr:.2f}  occupancy {tris / (64 * tr):.3f}")

@@ -14,7 +14,7 @@ def main(root):
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = row.get("Kernel_Name", "")
-                if "trace_kernel" not in k:
+                if "trace_" not in k or "kernel" not in k:
                     continue
                 name = row["Counter_Name"]
                 tot[k][name] += float(row["Counter_Value"])
