@@ -86,7 +86,7 @@ int check_params(const FfRenderParams* p)
 {
     if (!p) return fail(FF_ERR_INVALID_ARG, "render params are null");
     if (p->width <= 0 || p->height <= 0) return fail(FF_ERR_INVALID_ARG, "image size %dx%d is invalid", p->width, p->height);
-    if ((uint64_t)p->width * (uint64_t)p->height >= (1ull << 31)) return fail(FF_ERR_INVALID_ARG, "image too large");
+    if (p->width > 65535 || p->height > 65535) return fail(FF_ERR_INVALID_ARG, "image size %dx%d exceeds 65535 per side", p->width, p->height);
     if (p->bounces < 1 || p->bounces > 255) return fail(FF_ERR_INVALID_ARG, "bounces must be in 1..255 (got %d)", p->bounces);
     if (p->spp < 1 || p->spp >= (1 << 24)) return fail(FF_ERR_INVALID_ARG, "spp must be in 1..2^24-1 (got %d)", p->spp);
     if (p->trace_mode != FF_TRACE_BRUTE_FORCE && p->trace_mode != FF_TRACE_BVH) return fail(FF_ERR_INVALID_ARG, "unknown trace_mode %d", p->trace_mode);
@@ -276,7 +276,7 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_upload_scene: state is null");
     CompiledScene cs;
-    BvhBuildParams bp;
+    const BvhBuildParams bp = default_bvh_params();
     int st = compile_scene(host_geometries, n, bp, cs);
     if (st != FF_OK) return st;
     FF_HIP(hipSetDevice(s->device));

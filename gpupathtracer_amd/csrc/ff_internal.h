@@ -80,7 +80,11 @@ struct BvhBuildParams {
     int max_leaf_tris = 4; // <= 8
     int max_depth = 30;    // hard bound on inner-node depth (the traversal stack is sized from the built depth)
     int bins = 16;
+    float c_trav = 1.2f;   // SAH cost of an inner-node visit relative to one triangle test
 };
+
+// Defaults, overridable for experiments through FF_BVH_LEAF / FF_BVH_BINS / FF_BVH_CTRAV.
+BvhBuildParams default_bvh_params();
 
 // Build the object-space BVH of one mesh.  Appends inner nodes to `nodes` (breadth-first, root first) and the mesh's
 // triangles, in leaf order, to `tris`.  Returns the root inner-node index (into `nodes`) and the tree depth.

@@ -41,6 +41,7 @@ struct Best {
     int geom;
     int rec;
     float px, py, pz;
+    float cx, cy, cz; // object-space normal as found: cross(e1, e2) (not normalised) for a triangle, m_normal for a plane
 };
 
 // What a query carries while it is in flight: the exact distance and identity of the best resolved candidate.  The hit
@@ -118,6 +119,26 @@ __device__ __forceinline__ void consider(const GeomRecord& G, int g, int rec, in
         best.px = wx;
         best.py = wy;
         best.pz = wz;
+    }
+}
+
+// Object-space normal of a finished brute-force hit (the BVH path gets it from the exact evaluation of the winner).
+__device__ __forceinline__ void fill_object_normal(const GeomRecord* __restrict__ geoms, const TriRecord* __restrict__ tris, Best& best)
+{
+    if (best.geom < 0) return;
+    if (best.rec >= 0) {
+        const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)best.rec * 3;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        best.cx = e1y * e2z - e2y * e1z;
+        best.cy = e1z * e2x - e2z * e1x;
+        best.cz = e1x * e2y - e2x * e1y;
+    } else {
+        const GeomRecord& G = geoms[best.geom];
+        best.cx = G.plane_n[0];
+        best.cy = G.plane_n[1];
+        best.cz = G.plane_n[2];
     }
 }
 
@@ -322,8 +343,13 @@ __device__ __forceinline__ float inv_length(const Ray& r)
 // Exact reference evaluation (kernel.cu:35-125) of candidate (g, rec) for world ray wr: world distance and hit point.
 // Returns false if the exact test rejects it (cannot happen for a screened candidate; kept so that a wrong margin
 // could never corrupt a result).
-__device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, int g, int rec, float& dist, float& wx,
-                                          float& wy, float& wz, int& orig_tri)
+struct HitPoint {
+    float wx, wy, wz; // world-space point
+    float cx, cy, cz; // object-space normal as found (see Best)
+};
+
+__device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, int g, int rec, float& dist, HitPoint& H,
+                                          int& orig_tri)
 {
     Ray osr;
     float len;
@@ -335,32 +361,40 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
         const float4 a = tp[0], b = tp[1], c = tp[2];
         orig_tri = __float_as_int(a.w);
         t = triangle_t(a, b, c, osr);
+        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        H.cx = e1y * e2z - e2y * e1z; // kernel.cu:101 cross(edge1, edge2), shading normalises it where the reference does
+        H.cy = e1z * e2x - e2z * e1x;
+        H.cz = e1x * e2y - e2x * e1y;
     } else {
         const float4 pn = lds_geom4(L, g, 11);
         t = plane_t(pn.x, pn.y, pn.z, osr);
+        H.cx = pn.x; // kernel.cu:26
+        H.cy = pn.y;
+        H.cz = pn.z;
     }
     if (!(t > 0.0f)) return false;
     const float4 m0 = lds_geom4(L, g, 4), m1 = lds_geom4(L, g, 5), m2 = lds_geom4(L, g, 6), m3 = lds_geom4(L, g, 7);
     const float Px = osr.ox + osr.dx * t, Py = osr.oy + osr.dy * t, Pz = osr.oz + osr.dz * t; // kernel.cu:99 / :16
-    wx = (m0.x * Px + m1.x * Py) + (m2.x * Pz + m3.x);                                        // kernel.cu:113
-    wy = (m0.y * Px + m1.y * Py) + (m2.y * Pz + m3.y);
-    wz = (m0.z * Px + m1.z * Py) + (m2.z * Pz + m3.z);
-    const float vx = wr.ox - wx, vy = wr.oy - wy, vz = wr.oz - wz;
+    H.wx = (m0.x * Px + m1.x * Py) + (m2.x * Pz + m3.x);                                      // kernel.cu:113
+    H.wy = (m0.y * Px + m1.y * Py) + (m2.y * Pz + m3.y);
+    H.wz = (m0.z * Px + m1.z * Py) + (m2.z * Pz + m3.z);
+    const float vx = wr.ox - H.wx, vy = wr.oy - H.wy, vz = wr.oz - H.wz;
     dist = sqrtf((vx * vx + vy * vy) + vz * vz); // kernel.cu:114
     return true;
 }
 
 // Resolve the pending candidate exactly and merge it into `best` (kernel.cu:115-121).  Returns true if it became the
-// best; then (wx,wy,wz) is its hit point.
+// best; then H is its hit point and normal.
 __device__ __forceinline__ bool resolve_pending(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Pending& pend, BestId& best,
-                                                float& wx, float& wy, float& wz)
+                                                HitPoint& H)
 {
     const int g = pend.geom, rec = pend.rec;
     pend.geom = -1;
     pend.dist = kInf;
     float dist;
     int orig_tri;
-    if (!exact_hit(L, tris, wr, g, rec, dist, wx, wy, wz, orig_tri)) return false;
+    if (!exact_hit(L, tris, wr, g, rec, dist, H, orig_tri)) return false;
     bool take = dist < best.dist; // kernel.cu:115
     if (!take && dist == best.dist && best.geom >= 0) {
         // the reference keeps the first hit in (geometry, triangle) iteration order among equal distances
@@ -391,7 +425,12 @@ __device__ __forceinline__ bool offer(float d, int g, int rec, Pending& pend, co
     return false;
 }
 
-// Start a closest-hit query: screen all geometries, test the lane's candidate planes, remember its candidate meshes.
+// Start a closest-hit query: test every plane (fast form) and remember which meshes the ray can reach.
+//
+// Planes are screened in a wave-uniform loop (records through scalar loads, all lanes busy) WITHOUT the IEEE sqrt/divide
+// of kernel.cu:138: the hit position on the unit quad does not depend on the length of the object-space direction, so
+// the screen works on the un-normalised direction M^-1*d, for which the ray parameter is the world-space parameter.
+// Anything within the margins (quad edges, t ~ 0, |n.d| ~ 1e-7) is decided by the exact reference test at once.
 template <bool STATS>
 __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                               const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
@@ -406,60 +445,59 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     S.sp = 0;
     S.mesh = -1;
     S.resume = 0;
-    const WorldSlab ws = make_world_slab(wr);
+    const float wlen = __builtin_amdgcn_rcpf(inv_length(wr)); // |world direction| (1 for the integrator's rays)
 
-    // 1. screen every geometry's world box: wave-uniform loop over the global records (scalar loads)
-    unsigned long long cand = 0ull;
-    for (int g = 0; g < num_geoms; ++g) {
-        const GeomRecord& G = geoms[g];
-        if (slab_may_hit(G.wmin[0], G.wmin[1], G.wmin[2], G.wmax[0], G.wmax[1], G.wmax[2], ws, kInf)) cand |= 1ull << g;
+    for (int g = 0; g < num_planes; ++g) {
+        if (STATS) cnt.planes += 1;
+        // the record comes from the LDS copy at a wave-uniform address (broadcast reads; scalar loads from the global copy
+        // would serialise one ~L2-latency round trip per plane)
+        const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
+        const float4 pn = lds_geom4(L, g, 11);
+        // object-space origin and un-normalised direction (screening only: FMA form)
+        const float ox = __builtin_fmaf(c0.x, wr.ox, __builtin_fmaf(c1.x, wr.oy, __builtin_fmaf(c2.x, wr.oz, c3.x)));
+        const float oy = __builtin_fmaf(c0.y, wr.ox, __builtin_fmaf(c1.y, wr.oy, __builtin_fmaf(c2.y, wr.oz, c3.y)));
+        const float oz = __builtin_fmaf(c0.z, wr.ox, __builtin_fmaf(c1.z, wr.oy, __builtin_fmaf(c2.z, wr.oz, c3.z)));
+        const float ux = __builtin_fmaf(c0.x, wr.dx, __builtin_fmaf(c1.x, wr.dy, c2.x * wr.dz));
+        const float uy = __builtin_fmaf(c0.y, wr.dx, __builtin_fmaf(c1.y, wr.dy, c2.y * wr.dz));
+        const float uz = __builtin_fmaf(c0.z, wr.dx, __builtin_fmaf(c1.z, wr.dy, c2.z * wr.dz));
+        const float nx = pn.x, ny = pn.y, nz = pn.z;
+        const float dn = __builtin_fmaf(nx, ux, __builtin_fmaf(ny, uy, nz * uz));         // n . (M^-1 d)
+        const float num = -__builtin_fmaf(nx, ox, __builtin_fmaf(ny, oy, nz * oz));       // -(n . o')
+        const float len2 = __builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz));
+        // kernel.cu:12 |n.d'| >= 1e-7 with d' = u/len  <=>  dn^2 >= 1e-14 * len2
+        const float q = dn * dn, qlim = 1.0e-14f * len2;
+        const float ta = num * __builtin_amdgcn_rcpf(dn);                                 // world ray parameter of the plane
+        const float Pxa = __builtin_fmaf(ta, ux, ox), Pya = __builtin_fmaf(ta, uy, oy);
+        const float omag = fabsf(ox) + fabsf(oy) + fabsf(oz);
+        const float delta = 1.0e-5f * (1.0f + omag);
+        const float ex = fabsf(Pxa), ey = fabsf(Pya);
+        const bool front_sure = ta > 0.0f && fabsf(num) > 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz));
+        bool hit = ex <= 0.5f - delta && ey <= 0.5f - delta && front_sure && q >= qlim * 1.01f;
+        float dist = ta * wlen; // approximate world distance
+        if (!hit && ex <= 0.5f + delta && ey <= 0.5f + delta && q >= qlim * 0.99f && (front_sure || fabsf(num) <= 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz)))) {
+            // within a margin: decide with the exact reference test (kernel.cu:138 + :8-32)
+            Ray osr;
+            float len;
+            object_space_ray_lds(L, g, wr, osr, len);
+            const float tt = plane_t(nx, ny, nz, osr);
+            hit = tt > 0.0f;
+            dist = tt * wlen * __builtin_amdgcn_rcpf(len);
+        }
+        if (hit && offer(dist, g, -1, S.pend, S.best)) {
+            // two planes too close to rank approximately (a ray into an edge of the box): settle the held one exactly
+            HitPoint H;
+            resolve_pending(L, tris, wr, S.pend, S.best, H);
+            offer(dist, g, -1, S.pend, S.best);
+        }
     }
-    const unsigned long long plane_bits = num_planes >= 64 ? ~0ull : ((1ull << num_planes) - 1ull);
-    S.meshes = cand & ~plane_bits;
 
-    // 2. planes: each lane walks its own candidates (records gathered from LDS); the loop is wave-wide so that the rare
-    //    exact resolution of a near tie sits at loop level
-    unsigned long long pm = cand & plane_bits;
-    for (int round = 0; round < 4 * 64 && __ballot(pm != 0ull) != 0ull; ++round) { // each plane takes at most two rounds
-        bool conflict = false;
-        if (pm != 0ull) {
-            if (STATS) probe_round(cnt.plane_rounds);
-            const int g = __ffsll((long long)pm) - 1;
-            bool hit = false;
-            float ta = 0.f, len = 1.f;
-            const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-            if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, fminf(S.best.dist, S.pend.dist))) {
-                if (STATS) cnt.planes += 1;
-                Ray osr;
-                object_space_ray_lds(L, g, wr, osr, len);
-                const float4 pn = lds_geom4(L, g, 11);
-                const float denom = dot3(pn.x, pn.y, pn.z, osr.dx, osr.dy, osr.dz);         // kernel.cu:11 (exact)
-                if (fabsf(denom) >= kPlaneDenomMin) {                                        // kernel.cu:12 (exact)
-                    const float num = dot3(-osr.ox, -osr.oy, -osr.oz, pn.x, pn.y, pn.z);     // kernel.cu:14-15 numerator (exact)
-                    ta = num * __builtin_amdgcn_rcpf(denom);                                 // approximate t
-                    const float Pxa = __builtin_fmaf(ta, osr.dx, osr.ox), Pya = __builtin_fmaf(ta, osr.dy, osr.oy);
-                    const float delta = 1.0e-5f * fmaxf(1.0f, fabsf(ta));
-                    const float ex = fabsf(Pxa), ey = fabsf(Pya);
-                    if (ex <= 0.5f - delta && ey <= 0.5f - delta && ta > 1.0e-30f) {
-                        hit = true; // clearly inside the quad and in front of the origin
-                    } else if (ex <= 0.5f + delta && ey <= 0.5f + delta && ta > -1.0e-30f) {
-                        // within the margin of an edge (or t ~ 0): decide with the exact reference test
-                        const float tt = num / denom;
-                        const float Px = osr.ox + tt * osr.dx, Py = osr.oy + tt * osr.dy;
-                        hit = Px >= -0.5f && Px <= 0.5f && Py >= -0.5f && Py <= 0.5f && tt > 0.0f;
-                        ta = tt;
-                    }
-                }
-            }
-            if (hit) conflict = offer(ta * __builtin_amdgcn_rcpf(len * ws.inv_len), g, -1, S.pend, S.best);
-            if (!conflict) pm &= pm - 1ull; // done with this plane (a conflicting one is offered again after the resolve)
-        }
-        if (__ballot(conflict) != 0ull) {
-            if (conflict) {
-                float x, y, z;
-                resolve_pending(L, tris, wr, S.pend, S.best, x, y, z);
-            }
-        }
+    // meshes: conservative world-box test against what the planes already found
+    S.meshes = 0ull;
+    const WorldSlab ws = make_world_slab(wr);
+    const float limit = fminf(S.best.dist, S.pend.dist);
+    for (int g = num_planes; g < num_geoms; ++g) {
+        const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
+        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1ull << g;
     }
 }
 
@@ -580,17 +618,19 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
 __device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Best& best)
 {
     bool have_point = false;
-    best.px = best.py = best.pz = 0.0f;
-    if (S.pend.geom >= 0) have_point = resolve_pending(L, tris, wr, S.pend, S.best, best.px, best.py, best.pz);
+    HitPoint H = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    if (S.pend.geom >= 0) have_point = resolve_pending(L, tris, wr, S.pend, S.best, H);
     if (!have_point && S.best.geom >= 0) {
         // the winner was resolved earlier (two candidates had been too close to rank approximately): recompute its point
         float dist;
         int orig_tri;
-        exact_hit(L, tris, wr, S.best.geom, S.best.rec, dist, best.px, best.py, best.pz, orig_tri);
+        exact_hit(L, tris, wr, S.best.geom, S.best.rec, dist, H, orig_tri);
     }
     best.dist = S.best.dist;
     best.geom = S.best.geom;
     best.rec = S.best.rec;
+    best.px = H.wx; best.py = H.wy; best.pz = H.wz;
+    best.cx = H.cx; best.cy = H.cy; best.cz = H.cz;
 }
 
 __device__ __forceinline__ bool segment_done(const Segment& S) { return S.cur == kDone && S.meshes == 0ull && S.resume == 0; }
@@ -619,8 +659,8 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
         if (S.cur < 0) leaf_step<STATS>(L, tris, wr, S, cnt);
         if (__ballot(S.resume > 0) != 0ull) {
             if (S.resume > 0) {
-                float x, y, z;
-                resolve_pending(L, tris, wr, S.pend, S.best, x, y, z);
+                HitPoint H;
+                resolve_pending(L, tris, wr, S.pend, S.best, H);
             }
         }
         if (rounds >= limit) break;
@@ -653,6 +693,8 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
     best.geom = -1;
     best.rec = -1;
     best.px = best.py = best.pz = 0.0f;
+    best.cx = best.cy = 0.0f;
+    best.cz = 1.0f;
     for (int g = 0; g < num_geoms; ++g) {
         const GeomRecord& G = geoms[g];
         Ray osr;
@@ -680,7 +722,10 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
             if (t > 0.0f) consider(G, g, -1, -1, t, osr, wr, geoms, tris, best);
         }
     }
-    if (live) cnt.rays += 1;
+    if (live) {
+        fill_object_normal(geoms, tris, best);
+        cnt.rays += 1;
+    }
 }
 
 // ---- shading --------------------------------------------------------------------------------------------------------
@@ -688,7 +733,7 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
 // What shading needs from the hit geometry's record.
 struct Material {
     float4 n0, n1, n2; // inverse-transpose columns (w = column3 * 0)
-    float4 plane_n, albedo, emission;
+    float4 albedo, emission;
     int bxdf_type;
 };
 
@@ -698,7 +743,6 @@ __device__ __forceinline__ Material material_lds(const Lds& L, int g)
     m.n0 = lds_geom4(L, g, 8);
     m.n1 = lds_geom4(L, g, 9);
     m.n2 = lds_geom4(L, g, 10);
-    m.plane_n = lds_geom4(L, g, 11);
     m.albedo = lds_geom4(L, g, 12);
     m.emission = lds_geom4(L, g, 13);
     m.bxdf_type = lds_geom_i4(L, g, 16).y;
@@ -711,7 +755,6 @@ __device__ __forceinline__ Material material_global(const GeomRecord& G)
     m.n0 = make_float4(G.nrm_c0[0], G.nrm_c0[1], G.nrm_c0[2], G.nrm_c0[3]);
     m.n1 = make_float4(G.nrm_c1[0], G.nrm_c1[1], G.nrm_c1[2], G.nrm_c1[3]);
     m.n2 = make_float4(G.nrm_c2[0], G.nrm_c2[1], G.nrm_c2[2], G.nrm_c2[3]);
-    m.plane_n = make_float4(G.plane_n[0], G.plane_n[1], G.plane_n[2], 0.f);
     m.albedo = make_float4(G.albedo[0], G.albedo[1], G.albedo[2], 0.f);
     m.emission = make_float4(G.emission[0], G.emission[1], G.emission[2], 0.f);
     m.bxdf_type = G.bxdf_type;
@@ -720,23 +763,16 @@ __device__ __forceinline__ Material material_global(const GeomRecord& G)
 
 // World-space normal of the closest hit: inverse(transpose(M)) * vec4(n_obj, 0)  (kernel.cu:117), with
 // n_obj = normalize(cross(e1, e2)) for triangles (kernel.cu:101) or the plane's m_normal (kernel.cu:26).
-__device__ __forceinline__ void world_normal(const Material& M, const TriRecord* __restrict__ tris, int rec, float& nx, float& ny, float& nz)
+// `unit_object_normal`: normalise a triangle's face normal in object space first (kernel.cu:101, what Intersect::m_normal
+// and the NORMAL_DEBUG shade carry); the path integrator transforms the raw cross product and normalises once in world space.
+__device__ __forceinline__ void world_normal(const Material& M, const Best& best, bool unit_object_normal, float& nx, float& ny, float& nz)
 {
-    float ox, oy, oz;
-    if (rec >= 0) {
-        const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)rec * 3;
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-        const float cx = e1y * e2z - e2y * e1z, cy = e1z * e2x - e2z * e1x, cz = e1x * e2y - e2x * e1y;
-        const float inv = 1.0f / sqrtf(dot3(cx, cy, cz, cx, cy, cz));
-        ox = cx * inv;
-        oy = cy * inv;
-        oz = cz * inv;
-    } else {
-        ox = M.plane_n.x;
-        oy = M.plane_n.y;
-        oz = M.plane_n.z;
+    float ox = best.cx, oy = best.cy, oz = best.cz;
+    if (best.rec >= 0 && unit_object_normal) {
+        const float inv = 1.0f / sqrtf(dot3(ox, oy, oz, ox, oy, oz));
+        ox = ox * inv;
+        oy = oy * inv;
+        oz = oz * inv;
     }
     nx = (M.n0.x * ox + M.n1.x * oy) + (M.n2.x * oz + M.n0.w);
     ny = (M.n0.y * ox + M.n1.y * oy) + (M.n2.y * oz + M.n1.w);
@@ -752,9 +788,9 @@ __device__ __forceinline__ void philox2x32_10(unsigned c0, unsigned c1, unsigned
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         if (r > 0) key += 0x9E3779B9u;
-        const unsigned hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-        c0 = hi ^ key ^ c1;
-        c1 = lo;
+        const unsigned long long prod = (unsigned long long)c0 * 0xD256D193ull; // one v_mad_u64_u32 yields both halves
+        c0 = (unsigned)(prod >> 32) ^ key ^ c1;
+        c1 = (unsigned)prod;
     }
     o0 = c0;
     o1 = c1;
@@ -811,7 +847,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // Per-lane path state.
 struct Path {
     int lpix;      // local pixel index (row-major in the local image)
-    unsigned gpix; // global pixel index y*W+x (kernel.cu:191), the RNG counter
+    unsigned gxy;  // global pixel coordinates x | y << 16; the RNG counter is the pixel index y*W+x (kernel.cu:191)
     int s, b;      // current sample / segment
     Ray ray;       // current world-space ray
     float bx, by, bz; // throughput
@@ -819,9 +855,9 @@ struct Path {
 };
 
 // kernel.cu:197-205 for global pixel (x, y): origin = camera position, direction through the pixel corner.
-__device__ __forceinline__ void primary_ray(const KParams& p, unsigned gpix, Ray& ray)
+__device__ __forceinline__ void primary_ray(const KParams& p, unsigned gxy, Ray& ray)
 {
-    const int x = (int)(gpix % (unsigned)p.width), y = (int)(gpix / (unsigned)p.width);
+    const int x = (int)(gxy & 0xFFFFu), y = (int)(gxy >> 16);
     const float Px = ((float)x / p.screen_w) * 2.f - 1.f;  // :200
     const float Py = 1.f - ((float)y / p.screen_h) * 2.f;  // :201
     const float v0 = Px * p.far_clip, v1 = Py * p.far_clip, v2 = 1.f * p.far_clip, v3 = 1.f * p.far_clip;
@@ -841,7 +877,7 @@ __device__ __forceinline__ void primary_ray(const KParams& p, unsigned gpix, Ray
 __device__ __forceinline__ void start_sample(const KParams& p, Path& P)
 {
     P.b = 0;
-    primary_ray(p, P.gpix, P.ray);
+    primary_ray(p, P.gxy, P.ray);
     P.bx = P.by = P.bz = 1.f;
 }
 
@@ -873,7 +909,7 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                 if (lx < p.xlim && ly < p.local_rows && gy < p.ylim) {
                     got = true;
                     P.lpix = ly * p.width + lx;
-                    P.gpix = (unsigned)(gy * p.width + lx);
+                    P.gxy = (unsigned)lx | ((unsigned)gy << 16);
                     P.s = p.spp_begin;
                     if (p.first_chunk) {
                         P.ax = P.ay = P.az = 0.f;
@@ -900,7 +936,7 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
     float Lx = 0.f, Ly = 0.f, Lz = 0.f;
     if (hit) {
         float nx, ny, nz;
-        world_normal(M, p.tris, best.rec, nx, ny, nz);
+        world_normal(M, best, debug_shade, nx, ny, nz);
         if (debug_shade) {
             // shade(), kernel.cu:178-184
             Lx = fabsf(nx); Ly = fabsf(ny); Lz = fabsf(nz);
@@ -919,7 +955,8 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                 float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
                 if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; }
                 unsigned r0, r1;
-                philox2x32_10(P.gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
+                const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
+                philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
                 const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
                 float wlx, wly, wlz;
                 cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
@@ -932,13 +969,12 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                 const float wox = (t0 * wlx + s0 * wly) + ux * wlz;
                 const float woy = (t1 * wlx + s1 * wly) + uy * wlz;
                 const float woz = (t2 * wlx + s2 * wly) + uz * wlz;
-                const float winv = 1.0f / sqrtf(dot3(wox, woy, woz, wox, woy, woz));
                 P.ray.ox = best.px + ux * kRayEps;
                 P.ray.oy = best.py + uy * kRayEps;
                 P.ray.oz = best.pz + uz * kRayEps;
-                P.ray.dx = wox * winv;
-                P.ray.dy = woy * winv;
-                P.ray.dz = woz * winv;
+                P.ray.dx = wox; // unit local direction in an orthonormal basis: used as is (|wo| = 1 +- 1e-6)
+                P.ray.dy = woy;
+                P.ray.dz = woz;
                 ++P.b;
                 path_done = false;
             }
@@ -1004,7 +1040,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
 
 __device__ __forceinline__ void init_path(Path& P)
 {
-    P.lpix = 0; P.gpix = 0; P.s = 0; P.b = 0;
+    P.lpix = 0; P.gxy = 0; P.s = 0; P.b = 0;
     P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     P.bx = P.by = P.bz = 1.f;
     P.ax = P.ay = P.az = 0.f;
@@ -1037,34 +1073,55 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
     S.scale = 1.f;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
+    // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
+    unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
     for (;;) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (STATS) t0 = __builtin_amdgcn_s_memtime();
         // Lanes whose query is finished (or that have none) resolve + shade + spawn together; lanes still traversing skip.
-        if (!inflight || segment_done(S)) {
-            if (inflight) {
-                Best best;
-                finish_segment(L, p.tris, P.ray, S, best);
-                const bool hit = best.geom >= 0;
-                Material M;
-                if (hit) M = material_lds(L, best.geom);
-                else M.bxdf_type = FF_BXDF_COUNT;
-                active = shade_and_advance(p, best, hit, M, P);
-                inflight = false;
-            }
-            if (!active && !exhausted) {
-                active = acquire_pixel(p, lane, P);
-                exhausted = !active;
-            }
-            if (active) {
-                if (STATS) probe_round(cnt.segment_rounds);
-                begin_segment<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
-                cnt.rays += 1;
-                inflight = true;
-            }
+        const bool setup = !inflight || segment_done(S);
+        Best best;
+        bool hit = false;
+        if (setup && inflight) {
+            finish_segment(L, p.tris, P.ray, S, best);
+            hit = best.geom >= 0;
         }
+        if (STATS) t1 = __builtin_amdgcn_s_memtime();
+        if (setup && inflight) {
+            Material M;
+            if (hit) M = material_lds(L, best.geom);
+            else M.bxdf_type = FF_BXDF_COUNT;
+            active = shade_and_advance(p, best, hit, M, P);
+            inflight = false;
+        }
+        if (STATS) t2 = __builtin_amdgcn_s_memtime();
+        if (setup && !active && !exhausted) {
+            active = acquire_pixel(p, lane, P);
+            exhausted = !active;
+        }
+        if (STATS) t3 = __builtin_amdgcn_s_memtime();
+        if (setup && active) {
+            if (STATS) probe_round(cnt.segment_rounds);
+            begin_segment<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
+            cnt.rays += 1;
+            inflight = true;
+        }
+        if (STATS) t4 = __builtin_amdgcn_s_memtime();
         if (__ballot(inflight) == 0ull) break;
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
         // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
         if (inflight) traverse_budget<STATS>(L, p.tris, p.nodes, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold);
+        if (STATS) {
+            const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+            tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3; tphase[4] += t5 - t4;
+        }
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&p.counters[4], tphase[0]);
+        atomicAdd(&p.counters[5], tphase[1]);
+        atomicAdd(&p.counters[6], tphase[2]);
+        atomicAdd(&p.counters[7], tphase[3]);
+        atomicAdd(&p.counters[13], tphase[4]);
     }
     flush_counters(p, lane, cnt, STATS);
 }
@@ -1117,7 +1174,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
         wr.dx = r.m_direction.x; wr.dy = r.m_direction.y; wr.dz = r.m_direction.z;
     }
     Best best;
-    best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f;
+    best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
@@ -1134,7 +1191,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
         const GeomRecord& G = p.geoms[best.geom];
         const Material M = material_global(G);
         float nx, ny, nz;
-        world_normal(M, p.tris, best.rec, nx, ny, nz);
+        world_normal(M, best, true, nx, ny, nz);
         out.m_intersectionPoint.x = best.px; out.m_intersectionPoint.y = best.py; out.m_intersectionPoint.z = best.pz;
         out.m_normal.x = nx; out.m_normal.y = ny; out.m_normal.z = nz;
         out.m_t = best.dist;   // kernel.cu:119: the world distance

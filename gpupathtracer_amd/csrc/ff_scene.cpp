@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -134,7 +135,7 @@ struct Builder {
         int nleft = 0;
         if (best_axis >= 0) {
             const float parent_area = box.half_area();
-            const float c_trav = 1.2f, c_tri = 1.0f;
+            const float c_trav = P.c_trav, c_tri = 1.0f;
             const float split_cost = c_trav + (parent_area > 0.f ? best_cost / parent_area : (float)count) * c_tri;
             if (!must_split && split_cost >= (float)count * c_tri) return 0;
             const float lo = cb.mn[best_axis], sc = (float)NB / (cb.mx[best_axis] - cb.mn[best_axis]);
@@ -197,6 +198,15 @@ struct Builder {
 };
 
 } // namespace
+
+BvhBuildParams default_bvh_params()
+{
+    BvhBuildParams p;
+    if (const char* e = std::getenv("FF_BVH_LEAF")) p.max_leaf_tris = std::max(1, std::min(8, std::atoi(e)));
+    if (const char* e = std::getenv("FF_BVH_BINS")) p.bins = std::max(4, std::min(256, std::atoi(e)));
+    if (const char* e = std::getenv("FF_BVH_CTRAV")) p.c_trav = (float)std::atof(e);
+    return p;
+}
 
 int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams& params, std::vector<BvhNode>& nodes,
                    std::vector<TriRecord>& tris, int* out_depth)
@@ -446,7 +456,7 @@ extern "C" int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneIn
     if (!out) return fail(FF_ERR_INVALID_ARG, "ff_scene_info: out_info is null");
     std::memset(out, 0, sizeof *out);
     CompiledScene cs;
-    BvhBuildParams bp;
+    const BvhBuildParams bp = default_bvh_params();
     const int st = compile_scene(host_geometries, n, bp, cs);
     if (st != FF_OK) return st;
     out->num_geometries = (int)cs.geoms.size();

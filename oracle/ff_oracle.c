@@ -646,8 +646,26 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
             beta[1] = beta[1] * bx->m_albedo.y;
             beta[2] = beta[2] * bx->m_albedo.z;
             if (b == p->bounces - 1) break;
-            float nrm[3];
-            orc_normalize3(&is.m_normal.x, nrm);
+            /* Shading normal: the direction of inverse(transpose(M)) * n_obj, normalised once.  For triangles the
+             * un-normalised face normal cross(e1, e2) is transformed (the reference's Intersect carries its normalised
+             * value, K:101, which NORMAL_DEBUG shades; the direction is the same and one sqrt/divide per bounce is saved). */
+            float nobj[3], nw4[4], nrm[3];
+            const FfGeometry* hg = &geoms[is.geometryIndex];
+            if (is.triangleIndex >= 0) {
+                const FfTriangle* tr = &hg->m_triangles[is.triangleIndex];
+                float e1[3] = { tr->m_v1.x - tr->m_v0.x, tr->m_v1.y - tr->m_v0.y, tr->m_v1.z - tr->m_v0.z };
+                float e2[3] = { tr->m_v2.x - tr->m_v0.x, tr->m_v2.y - tr->m_v0.y, tr->m_v2.z - tr->m_v0.z };
+                orc_cross3(e1, e2, nobj);
+            } else {
+                nobj[0] = hg->m_normal.x; nobj[1] = hg->m_normal.y; nobj[2] = hg->m_normal.z;
+            }
+            {
+                float mt[16], nm[16], n4[4] = { nobj[0], nobj[1], nobj[2], 0.f };
+                orc_mat4_transpose(hg->m_modelMatrix.m, mt);
+                orc_mat4_inverse(mt, nm);
+                orc_mat4_mul_vec4(nm, n4, nw4);
+            }
+            orc_normalize3(nw4, nrm);
             if (orc_dot3(nrm, &ray.m_direction.x) > 0.f) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
             float u1, u2, wl[3], tt[3], bb[3];
             uint32_t k24;
@@ -655,13 +673,14 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
             (void)u2;
             orc_cosine_sample_hemisphere(u1, k24, wl);
             orc_onb(nrm, tt, bb);
+            /* the local direction is unit and the basis orthonormal: the world direction is used as is (|wo| = 1 +- 1e-6) */
             float wo[3] = { (tt[0] * wl[0] + bb[0] * wl[1]) + nrm[0] * wl[2],
                             (tt[1] * wl[0] + bb[1] * wl[1]) + nrm[1] * wl[2],
                             (tt[2] * wl[0] + bb[2] * wl[1]) + nrm[2] * wl[2] };
             ray.m_origin.x = is.m_intersectionPoint.x + nrm[0] * ORC_RAY_EPS;
             ray.m_origin.y = is.m_intersectionPoint.y + nrm[1] * ORC_RAY_EPS;
             ray.m_origin.z = is.m_intersectionPoint.z + nrm[2] * ORC_RAY_EPS;
-            orc_normalize3(wo, &ray.m_direction.x);
+            ray.m_direction.x = wo[0]; ray.m_direction.y = wo[1]; ray.m_direction.z = wo[2];
         }
         acc[0] = acc[0] + L[0];
         acc[1] = acc[1] + L[1];
