@@ -40,7 +40,7 @@ struct FfState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
-    int setup_threshold = 12, leaf_threshold = 64; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
+    int setup_threshold = 14, leaf_threshold = 16; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
     unsigned long long raw_counters[16] = {};
@@ -158,7 +158,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.tris = s->d_tris;
     k.nodes = s->d_nodes;
     const int block_threads = prm->trace_mode == FF_TRACE_BVH ? s->block_threads : kBlockThreads;
-    k.stack_depth = s->max_depth + 2;
+    k.stack_depth = s->max_depth + 1; // at most one pending sibling per level above the cursor, plus one spare slot
     const int fit = max_lds_nodes(k.stack_depth, block_threads, s->num_geoms);
     k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;
     if (k.lds_nodes < 0) k.lds_nodes = 0;
@@ -403,7 +403,7 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.geoms = s->d_geoms;
     p.tris = s->d_tris;
     p.nodes = s->d_nodes;
-    p.stack_depth = s->max_depth + 2;
+    p.stack_depth = s->max_depth + 1;
     const int fit = max_lds_nodes(p.stack_depth, kBlockThreads, s->num_geoms);
     p.lds_nodes = s->num_nodes < fit ? s->num_nodes : (fit > 0 ? fit : 0);
     e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);

@@ -326,7 +326,7 @@ struct Pending {
 struct Segment {
     BestId best;
     Pending pend;
-    unsigned long long meshes; // candidate meshes not started yet (bit = record index)
+    unsigned meshes;           // candidate meshes not started yet (bit = record index; BVH mode handles <= 32 geometries)
     int cur, sp, mesh;         // traversal cursor (inner >= 0, leaf < 0, kDone), stack height, record index of the current mesh
     Ray osr;                   // object-space ray of the current mesh
     float ix, iy, iz, ox, oy, oz; // 1/d and -o/d of osr (box tests)
@@ -492,20 +492,20 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     }
 
     // meshes: conservative world-box test against what the planes already found
-    S.meshes = 0ull;
+    S.meshes = 0u;
     const WorldSlab ws = make_world_slab(wr);
     const float limit = fminf(S.best.dist, S.pend.dist);
     for (int g = num_planes; g < num_geoms; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1ull << g;
+        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << g;
     }
 }
 
 // Idle lane with candidate meshes left: enter the next one.
 __device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Segment& S)
 {
-    const int g = __ffsll((long long)S.meshes) - 1;
-    S.meshes &= S.meshes - 1ull;
+    const int g = __ffs((int)S.meshes) - 1;
+    S.meshes &= S.meshes - 1u;
     const int root = lds_geom_i4(L, g, 17).x;
     if (root < 0) return;
     float len;
@@ -633,7 +633,7 @@ __device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __
     best.cx = H.cx; best.cy = H.cy; best.cz = H.cz;
 }
 
-__device__ __forceinline__ bool segment_done(const Segment& S) { return S.cur == kDone && S.meshes == 0ull && S.resume == 0; }
+__device__ __forceinline__ bool segment_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
 
 // Advance the queries of the calling lanes: mesh starts, inner-node phases, leaf phases and near-tie resolutions alternate
 // wave-wide until every calling lane is done or `budget` inner-node rounds have been spent (budget <= 0: no limit).
@@ -645,7 +645,7 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
     const int limit = budget > 0 ? budget : kLoopGuard;
     int rounds = 0, guard = 0;
     for (;;) {
-        while (S.cur == kDone && S.meshes != 0ull) start_next_mesh(L, wr, S);
+        while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
         if (__ballot(S.cur != kDone) == 0ull) break;
         for (;;) {
             const bool inner = S.cur >= 0 && S.cur != kDone;
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     Segment S;
     S.best = { kInf, -1, -1 };
     S.pend = { kInf, -1, -1 };
-    S.meshes = 0ull;
+    S.meshes = 0u;
     S.cur = kDone; S.sp = 0; S.mesh = -1; S.resume = 0;
     S.osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;

@@ -467,7 +467,7 @@ extern "C" int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneIn
     out->bvh_nodes = (int)cs.nodes.size();
     out->bvh_max_depth = cs.max_depth;
     out->num_triangles = cs.tris.size();
-    const int stack_depth = cs.max_depth + 2;
+    const int stack_depth = cs.max_depth + 1;
     out->lds_nodes = std::min((int)cs.nodes.size(), std::max(0, max_lds_nodes(stack_depth, 512, (int)cs.geoms.size())));
     out->lds_bytes = (int)bvh_lds_bytes(out->lds_nodes, stack_depth, 512, (int)cs.geoms.size());
     out->device_bytes = cs.geoms.size() * sizeof(GeomRecord) + cs.tris.size() * sizeof(TriRecord) + cs.nodes.size() * sizeof(BvhNode);
