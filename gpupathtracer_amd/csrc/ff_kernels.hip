@@ -730,42 +730,29 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
 
 // ---- shading --------------------------------------------------------------------------------------------------------
 
-// What shading needs from the hit geometry's record.
-struct Material {
-    float4 n0, n1, n2; // inverse-transpose columns (w = column3 * 0)
-    float4 albedo, emission;
-    int bxdf_type;
+// What shading needs from the hit geometry's record, fetched piece by piece when it is used (loading the whole record up
+// front costs ~25 registers at the kernel's pressure peak).  BVH kernels read the LDS copy, brute-force kernels the
+// global one.
+struct MaterialRef {
+    const GeomRecord* global; // non-null: read the global record
+    Lds lds;                  // else: LDS copy
+    int g;
 };
 
-__device__ __forceinline__ Material material_lds(const Lds& L, int g)
+__device__ __forceinline__ float4 mat_f4(const MaterialRef& M, int k)
 {
-    Material m;
-    m.n0 = lds_geom4(L, g, 8);
-    m.n1 = lds_geom4(L, g, 9);
-    m.n2 = lds_geom4(L, g, 10);
-    m.albedo = lds_geom4(L, g, 12);
-    m.emission = lds_geom4(L, g, 13);
-    m.bxdf_type = lds_geom_i4(L, g, 16).y;
-    return m;
+    if (M.global) return reinterpret_cast<const float4*>(M.global)[k];
+    return lds_geom4(M.lds, M.g, k);
+}
+__device__ __forceinline__ int mat_bxdf(const MaterialRef& M)
+{
+    if (M.global) return M.global->bxdf_type;
+    return lds_geom_i4(M.lds, M.g, 16).y;
 }
 
-__device__ __forceinline__ Material material_global(const GeomRecord& G)
-{
-    Material m;
-    m.n0 = make_float4(G.nrm_c0[0], G.nrm_c0[1], G.nrm_c0[2], G.nrm_c0[3]);
-    m.n1 = make_float4(G.nrm_c1[0], G.nrm_c1[1], G.nrm_c1[2], G.nrm_c1[3]);
-    m.n2 = make_float4(G.nrm_c2[0], G.nrm_c2[1], G.nrm_c2[2], G.nrm_c2[3]);
-    m.albedo = make_float4(G.albedo[0], G.albedo[1], G.albedo[2], 0.f);
-    m.emission = make_float4(G.emission[0], G.emission[1], G.emission[2], 0.f);
-    m.bxdf_type = G.bxdf_type;
-    return m;
-}
-
-// World-space normal of the closest hit: inverse(transpose(M)) * vec4(n_obj, 0)  (kernel.cu:117), with
-// n_obj = normalize(cross(e1, e2)) for triangles (kernel.cu:101) or the plane's m_normal (kernel.cu:26).
 // `unit_object_normal`: normalise a triangle's face normal in object space first (kernel.cu:101, what Intersect::m_normal
 // and the NORMAL_DEBUG shade carry); the path integrator transforms the raw cross product and normalises once in world space.
-__device__ __forceinline__ void world_normal(const Material& M, const Best& best, bool unit_object_normal, float& nx, float& ny, float& nz)
+__device__ __forceinline__ void world_normal(const MaterialRef& M, const Best& best, bool unit_object_normal, float& nx, float& ny, float& nz)
 {
     float ox = best.cx, oy = best.cy, oz = best.cz;
     if (best.rec >= 0 && unit_object_normal) {
@@ -774,9 +761,10 @@ __device__ __forceinline__ void world_normal(const Material& M, const Best& best
         oy = oy * inv;
         oz = oz * inv;
     }
-    nx = (M.n0.x * ox + M.n1.x * oy) + (M.n2.x * oz + M.n0.w);
-    ny = (M.n0.y * ox + M.n1.y * oy) + (M.n2.y * oz + M.n1.w);
-    nz = (M.n0.z * ox + M.n1.z * oy) + (M.n2.z * oz + M.n2.w);
+    const float4 n0 = mat_f4(M, 8), n1 = mat_f4(M, 9), n2 = mat_f4(M, 10); // inverse-transpose columns (w = column3 * 0)
+    nx = (n0.x * ox + n1.x * oy) + (n2.x * oz + n0.w);
+    ny = (n0.y * ox + n1.y * oy) + (n2.y * oz + n1.w);
+    nz = (n0.z * ox + n1.z * oy) + (n2.z * oz + n2.w);
 }
 
 // ---- build-defined integrator pieces (DESIGN.md "Integrator"; mirrored by the oracle) ------------------------------
@@ -927,7 +915,7 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
 
 // Shade the finished segment and advance the path.  Returns true when the lane still owns its pixel (either the path
 // continues with a new ray in P.ray, or the next sample's primary ray was generated), false when the pixel is finished.
-__device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& best, bool hit, const Material& M, Path& P)
+__device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
 {
     const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
     bool path_done = true;
@@ -940,16 +928,18 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
         if (debug_shade) {
             // shade(), kernel.cu:178-184
             Lx = fabsf(nx); Ly = fabsf(ny); Lz = fabsf(nz);
-        } else if (M.bxdf_type == FF_BXDF_EMITTER) {
+        } else if (mat_bxdf(M) == FF_BXDF_EMITTER) {
             // utilities.h:96-103: two-sided emitter, m_emissiveColor * m_intensity
-            Lx = 0.f + P.bx * M.emission.x;
-            Ly = 0.f + P.by * M.emission.y;
-            Lz = 0.f + P.bz * M.emission.z;
+            const float4 emission = mat_f4(M, 13);
+            Lx = 0.f + P.bx * emission.x;
+            Ly = 0.f + P.by * emission.y;
+            Lz = 0.f + P.bz * emission.z;
         } else {
             // everything else is diffuse (utilities.h:109); cosine-weighted sampling, so f*cos/pdf = albedo
-            P.bx = P.bx * M.albedo.x;
-            P.by = P.by * M.albedo.y;
-            P.bz = P.bz * M.albedo.z;
+            const float4 albedo = mat_f4(M, 12);
+            P.bx = P.bx * albedo.x;
+            P.by = P.by * albedo.y;
+            P.bz = P.bz * albedo.z;
             if (P.b != p.bounces - 1) {
                 const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
                 float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
@@ -1088,9 +1078,10 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         }
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
         if (setup && inflight) {
-            Material M;
-            if (hit) M = material_lds(L, best.geom);
-            else M.bxdf_type = FF_BXDF_COUNT;
+            MaterialRef M;
+            M.global = nullptr;
+            M.lds = L;
+            M.g = best.geom;
             active = shade_and_advance(p, best, hit, M, P);
             inflight = false;
         }
@@ -1149,9 +1140,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
         closest_hit_brute<STATS>(p.geoms, p.num_geoms, p.tris, batch, active, P.ray, best, cnt);
         if (!active) continue;
         const bool hit = best.geom >= 0;
-        Material M;
-        if (hit) M = material_global(p.geoms[best.geom]);
-        else M.bxdf_type = FF_BXDF_COUNT;
+        MaterialRef M;
+        M.global = hit ? &p.geoms[best.geom] : p.geoms;
+        M.lds = make_lds(0, 0, kBlockThreads, tid);
+        M.g = 0;
         active = shade_and_advance(p, best, hit, M, P);
     }
     flush_counters(p, lane, cnt, STATS);
@@ -1189,7 +1181,10 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     out.triangleIndex = -1; // :65
     if (best.geom >= 0) {
         const GeomRecord& G = p.geoms[best.geom];
-        const Material M = material_global(G);
+        MaterialRef M;
+        M.global = &G;
+        M.lds = L;
+        M.g = 0;
         float nx, ny, nz;
         world_normal(M, best, true, nx, ny, nz);
         out.m_intersectionPoint.x = best.px; out.m_intersectionPoint.y = best.py; out.m_intersectionPoint.z = best.pz;
