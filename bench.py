@@ -88,11 +88,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # FF_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices and the gather goes
+    # through host memory); the real multi-GPU run uses nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("FF_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier_sync():
         if world > 1:
@@ -108,7 +115,7 @@ def main():
     mode = T.TRACE_BVH if args.trace_mode == "bvh" else T.TRACE_BRUTE_FORCE
     params = lib.render_params(args.width, args.height, args.bounces, args.spp, args.seed, mode, T.SHADE_DIFFUSE_PATH,
                                T.GRID_FULL, args.spp_per_launch)
-    tracer = lib.Tracer(local_rank)
+    tracer = lib.Tracer(dev_index)
     tracer.upload_scene(scene)
     tracer.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -123,8 +130,14 @@ def main():
         tracer.render_strips_device(camera, params, strip_rows, rank, world, rgb8.data_ptr(), rad.data_ptr())
         if world > 1:
             # framebuffer gather over RCCL/xGMI to the rank that owns the display buffer, then strip de-interleave
-            g8 = ffdist.gather_strips(rgb8[:local_rows], args.height, strip_rows, rank, world, dist)
-            gr = ffdist.gather_strips(rad[:local_rows], args.height, strip_rows, rank, world, dist)
+            if backend == "nccl":
+                g8 = ffdist.gather_strips(rgb8[:local_rows], args.height, strip_rows, rank, world, dist)
+                gr = ffdist.gather_strips(rad[:local_rows], args.height, strip_rows, rank, world, dist)
+            else:
+                g8 = ffdist.gather_strips(rgb8[:local_rows].cpu(), args.height, strip_rows, rank, world, dist)
+                gr = ffdist.gather_strips(rad[:local_rows].cpu(), args.height, strip_rows, rank, world, dist)
+                if rank == 0:
+                    g8, gr = g8.to(device), gr.to(device)
             if rank == 0:
                 tracer.deinterleave_strips(g8.data_ptr(), full_rgb8.data_ptr(), args.width, args.height, strip_rows, world, 3)
                 tracer.deinterleave_strips(gr.data_ptr(), full_rad.data_ptr(), args.width, args.height, strip_rows, world, 12)
@@ -152,11 +165,12 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        red_dev = device if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         agg = torch.tensor([float(rays), kernel_ms, float(counted.rays_traced), float(counted.nodes_visited), float(counted.tris_tested)],
-                           dtype=torch.float64, device=device)
+                           dtype=torch.float64, device=red_dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         total_rays = agg[0].item()
     else:
