@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ff_internal.h"
@@ -251,5 +252,177 @@ int ff_load_obj(const char* path, FfTriangle** out_triangles, int* out_count)
 }
 
 void ff_free_triangles(FfTriangle* triangles) { std::free(triangles); }
+
+} // extern "C"
+
+// -------------------------------------------------------------------------------------------------
+// Scene description file (the reference's "TODO: Load scene from file", kernel.cu:261).
+// -------------------------------------------------------------------------------------------------
+
+struct FfSceneFile {
+    std::vector<FfGeometry> geometries;
+    std::vector<FfTriangle*> meshes;              // malloc'ed by ff_load_obj
+    std::vector<std::pair<std::string, FfBXDF*>> bxdfs; // stable addresses
+    FfCamera camera;                               // width/height filled per request
+    ~FfSceneFile()
+    {
+        for (FfTriangle* t : meshes) std::free(t);
+        for (auto& b : bxdfs) delete b.second;
+    }
+};
+
+namespace {
+
+std::vector<std::string> split_ws(const std::string& line)
+{
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r' || line[i] == '\n')) ++i;
+        if (i >= line.size() || line[i] == '#') break;
+        size_t j = i;
+        while (j < line.size() && line[j] != ' ' && line[j] != '\t' && line[j] != '\r' && line[j] != '\n') ++j;
+        out.push_back(line.substr(i, j - i));
+        i = j;
+    }
+    return out;
+}
+
+bool read_floats(const std::vector<std::string>& tok, size_t& i, int n, float* out)
+{
+    for (int k = 0; k < n; ++k) {
+        if (i >= tok.size()) return false;
+        char* end = nullptr;
+        out[k] = (float)std::strtod(tok[i].c_str(), &end);
+        if (end == tok[i].c_str() || *end != '\0') return false;
+        ++i;
+    }
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int ff_scene_file_load(const char* path, FfSceneFile** out_scene)
+{
+    ff::clear_error();
+    if (!path || !out_scene) return ff::fail(FF_ERR_INVALID_ARG, "ff_scene_file_load: null argument");
+    *out_scene = nullptr;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return ff::fail(FF_ERR_IO, "ff_scene_file_load: cannot open '%s': %s", path, std::strerror(errno));
+    std::string dir(path);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+
+    FfSceneFile* sc = new FfSceneFile();
+    ff_camera_init_default(&sc->camera, 1, 1); // kernel.cu:312-321 literals
+    char buf[4096];
+    int lineno = 0, status = FF_OK;
+    auto bad = [&](const char* what) {
+        status = ff::fail(FF_ERR_IO, "%s:%d: %s", path, lineno, what);
+    };
+    while (status == FF_OK && std::fgets(buf, sizeof buf, f)) {
+        ++lineno;
+        const std::vector<std::string> tok = split_ws(buf);
+        if (tok.empty()) continue;
+        size_t i = 1;
+        if (tok[0] == "camera") {
+            while (status == FF_OK && i < tok.size()) {
+                const std::string key = tok[i++];
+                float v[3];
+                if (key == "position") { if (!read_floats(tok, i, 3, v)) bad("camera position needs 3 numbers"); else sc->camera.m_position = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "yaw") { if (!read_floats(tok, i, 1, v)) bad("yaw needs a number"); else sc->camera.m_yaw = v[0]; }
+                else if (key == "pitch") { if (!read_floats(tok, i, 1, v)) bad("pitch needs a number"); else sc->camera.m_pitch = v[0]; }
+                else if (key == "fov") { if (!read_floats(tok, i, 1, v)) bad("fov needs a number"); else sc->camera.m_fov = v[0]; }
+                else if (key == "near") { if (!read_floats(tok, i, 1, v)) bad("near needs a number"); else sc->camera.m_nearClip = v[0]; }
+                else if (key == "far") { if (!read_floats(tok, i, 1, v)) bad("far needs a number"); else sc->camera.m_farClip = v[0]; }
+                else bad("unknown camera key");
+            }
+        } else if (tok[0] == "bxdf") {
+            if (tok.size() < 3) { bad("bxdf needs a name and a type"); break; }
+            FfBXDF* b = new FfBXDF();
+            ff_bxdf_init(b);
+            const std::string& type = tok[2];
+            if (type == "diffuse") b->m_type = FF_BXDF_DIFFUSE;
+            else if (type == "emitter") b->m_type = FF_BXDF_EMITTER;
+            else if (type == "mirror") b->m_type = FF_BXDF_MIRROR;
+            else if (type == "glass") b->m_type = FF_BXDF_GLASS;
+            else { delete b; bad("unknown bxdf type"); break; }
+            sc->bxdfs.emplace_back(tok[1], b);
+            i = 3;
+            while (status == FF_OK && i < tok.size()) {
+                const std::string key = tok[i++];
+                float v[3];
+                if (key == "albedo") { if (!read_floats(tok, i, 3, v)) bad("albedo needs 3 numbers"); else b->m_albedo = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "color") { if (!read_floats(tok, i, 3, v)) bad("color needs 3 numbers"); else b->m_emissiveColor = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "intensity") { if (!read_floats(tok, i, 1, v)) bad("intensity needs a number"); else b->m_intensity = v[0]; }
+                else bad("unknown bxdf key");
+            }
+        } else if (tok[0] == "mesh" || tok[0] == "plane") {
+            const bool is_mesh = tok[0] == "mesh";
+            FfTriangle* tris = nullptr;
+            int ntris = 0;
+            if (is_mesh) {
+                if (tok.size() < 2) { bad("mesh needs an OBJ path"); break; }
+                const std::string obj = (!tok[1].empty() && tok[1][0] == '/') ? tok[1] : dir + tok[1];
+                const int st = ff_load_obj(obj.c_str(), &tris, &ntris);
+                if (st != FF_OK) { status = st; break; }
+                sc->meshes.push_back(tris);
+                i = 2;
+            }
+            FfVec3 pos{ 0, 0, 0 }, rot{ 0, 0, 0 }, scl{ 1, 1, 1 };
+            FfBXDF* bx = nullptr;
+            while (status == FF_OK && i < tok.size()) {
+                const std::string key = tok[i++];
+                float v[3];
+                if (key == "position") { if (!read_floats(tok, i, 3, v)) bad("position needs 3 numbers"); else pos = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "rotation") { if (!read_floats(tok, i, 3, v)) bad("rotation needs 3 numbers"); else rot = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "scale") { if (!read_floats(tok, i, 3, v)) bad("scale needs 3 numbers"); else scl = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "bxdf") {
+                    if (i >= tok.size()) { bad("bxdf needs a name"); break; }
+                    for (auto& b : sc->bxdfs) if (b.first == tok[i]) bx = b.second;
+                    if (!bx) bad("bxdf name not defined above");
+                    ++i;
+                } else bad("unknown geometry key");
+            }
+            if (status != FF_OK) break;
+            if (!bx) { bad("geometry needs a bxdf"); break; }
+            FfGeometry g;
+            ff_geometry_init(&g, is_mesh ? FF_GEOM_TRIANGLEMESH : FF_GEOM_PLANE, pos, rot, scl, tris, ntris, 0.f);
+            g.m_bxdf = bx;
+            sc->geometries.push_back(g);
+        } else {
+            bad("unknown statement");
+        }
+    }
+    std::fclose(f);
+    if (status == FF_OK && sc->geometries.empty()) status = ff::fail(FF_ERR_IO, "%s: no geometries", path);
+    if (status != FF_OK) {
+        delete sc;
+        return status;
+    }
+    *out_scene = sc;
+    return FF_OK;
+}
+
+const FfGeometry* ff_scene_file_geometries(const FfSceneFile* scene, int* out_count)
+{
+    if (out_count) *out_count = scene ? (int)scene->geometries.size() : 0;
+    return scene ? scene->geometries.data() : nullptr;
+}
+
+int ff_scene_file_camera(const FfSceneFile* scene, int width, int height, FfCamera* out_camera)
+{
+    ff::clear_error();
+    if (!scene || !out_camera) return ff::fail(FF_ERR_INVALID_ARG, "ff_scene_file_camera: null argument");
+    *out_camera = scene->camera;
+    out_camera->m_screenWidth = (float)width;
+    out_camera->m_screenHeight = (float)height;
+    ff_camera_update_basis(out_camera);
+    return FF_OK;
+}
+
+void ff_scene_file_free(FfSceneFile* scene) { delete scene; }
 
 } // extern "C"

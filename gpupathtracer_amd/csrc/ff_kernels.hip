@@ -57,6 +57,7 @@ struct Counters {
     // occupancy probes (instrumented launches only): wave-level rounds of each phase.  The active-lane totals of the
     // phases are the counters above (nodes = inner-step lanes, tris = triangle-test lanes, planes, rays).
     unsigned inner_rounds, leaf_rounds, tri_rounds, plane_rounds, segment_rounds;
+    unsigned no_mesh; // queries that needed no mesh traversal (planes only)
 };
 
 // Count one wave-level round of a phase: exactly one of the active lanes (the lowest) records it.
@@ -499,6 +500,7 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
         if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << g;
     }
+    if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
 }
 
 // Idle lane with candidate meshes left: enter the next one.
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
                                  pl = wave_sum((unsigned long long)cnt.planes);
         const unsigned long long r0 = wave_sum((unsigned long long)cnt.inner_rounds), r1 = wave_sum((unsigned long long)cnt.leaf_rounds),
                                  r2 = wave_sum((unsigned long long)cnt.tri_rounds), r3 = wave_sum((unsigned long long)cnt.plane_rounds),
-                                 r4 = wave_sum((unsigned long long)cnt.segment_rounds);
+                                 r4 = wave_sum((unsigned long long)cnt.segment_rounds), r5 = wave_sum((unsigned long long)cnt.no_mesh);
         if (lane == 0) {
             if (n) atomicAdd(&p.counters[1], n);
             if (t) atomicAdd(&p.counters[2], t);
@@ -1024,6 +1026,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
             atomicAdd(&p.counters[10], r2);
             atomicAdd(&p.counters[11], r3);
             atomicAdd(&p.counters[12], r4);
+            atomicAdd(&p.counters[14], r5);
         }
     }
 }
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     Segment S;
@@ -1125,7 +1128,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     bool active = false, exhausted = false;
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     }
     Best best;
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
     if (!live) return;

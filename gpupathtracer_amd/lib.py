@@ -20,6 +20,7 @@ EXPORTS = [
     "ff_upload_scene", "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_load_obj", "ff_free_triangles",
+    "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
 ]
 
 _lib = None
@@ -75,6 +76,12 @@ def load():
     lib.ff_load_obj.argtypes = [C.c_char_p, P(P(T.FfTriangle)), P(i32)]
     lib.ff_free_triangles.argtypes = [P(T.FfTriangle)]
     lib.ff_free_triangles.restype = None
+    lib.ff_scene_file_load.argtypes = [C.c_char_p, P(vp)]
+    lib.ff_scene_file_geometries.argtypes = [vp, P(i32)]
+    lib.ff_scene_file_geometries.restype = P(T.FfGeometry)
+    lib.ff_scene_file_camera.argtypes = [vp, i32, i32, P(T.FfCamera)]
+    lib.ff_scene_file_free.argtypes = [vp]
+    lib.ff_scene_file_free.restype = None
     _lib = lib
     return lib
 
@@ -96,10 +103,47 @@ def load_obj(path):
         lib.ff_free_triangles(ptr)
 
 
+class SceneFile:
+    """A scene description file (ff_scene_file_load): exposes `.geometries` / `len()` like scenes.Scene."""
+
+    def __init__(self, path):
+        self._lib = load()
+        self._handle = C.c_void_p()
+        check(self._lib.ff_scene_file_load(os.fsencode(path), C.byref(self._handle)))
+        n = C.c_int(0)
+        self.geometries = self._lib.ff_scene_file_geometries(self._handle, C.byref(n))
+        self._count = n.value
+
+    def __len__(self):
+        return self._count
+
+    @property
+    def triangle_count(self):
+        return int(sum(self.geometries[i].m_numberOfTriangles for i in range(self._count)
+                       if self.geometries[i].m_geometryType == T.GEOM_TRIANGLEMESH))
+
+    def camera(self, width, height):
+        cam = T.FfCamera()
+        check(self._lib.ff_scene_file_camera(self._handle, width, height, C.byref(cam)))
+        return cam
+
+    def close(self):
+        if self._handle:
+            self._lib.ff_scene_file_free(self._handle)
+            self._handle = C.c_void_p()
+            self.geometries = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def scene_info(scene):
     """Host-only dry run of the scene compiler (sizes, BVH shape, structural self-check)."""
     info = T.FfSceneInfo()
-    check(load().ff_scene_info(scene.geometries, len(scene.geometries), C.byref(info)))
+    check(load().ff_scene_info(scene.geometries, len(scene), C.byref(info)))
     return info
 
 
@@ -140,7 +184,7 @@ class Tracer:
 
     def upload_scene(self, scene):
         """scene: gpupathtracer_amd.scenes.Scene"""
-        check(self._lib.ff_upload_scene(self._state, scene.geometries, len(scene.geometries)))
+        check(self._lib.ff_upload_scene(self._state, scene.geometries, len(scene)))
 
     def set_collect_stats(self, on):
         check(self._lib.ff_set_collect_stats(self._state, 1 if on else 0))

@@ -161,6 +161,25 @@ FF_API int ff_debug_counters(FfState* state, unsigned long long* out16);
 FF_API int ff_load_obj(const char* path, FfTriangle** out_triangles, int* out_count);
 FF_API void ff_free_triangles(FfTriangle* triangles);
 
+/* ---- scene description file (next-row scope: the reference's "TODO: Load scene from file", kernel.cu:261) -------- */
+
+/* A scene file replaces the literals of kernel.cu:227-259 (geometries, BXDFs) and kernel.cu:311-321 (camera).  Plain text,
+ * one statement per line, '#' starts a comment:
+ *
+ *   camera position X Y Z yaw DEG pitch DEG fov DEG near N far F            (every key optional: kernel.cu:312-321 defaults)
+ *   bxdf NAME diffuse|emitter|mirror|glass [albedo R G B] [color R G B] [intensity I]
+ *   mesh FILE.obj [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME (path relative to the scene file)
+ *   plane [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME
+ *
+ * Geometries keep file order (it is the reference's iteration order, kernel.cu:133).  The returned object owns the
+ * triangles and BXDFs its FfGeometry array points to. */
+typedef struct FfSceneFile FfSceneFile;
+FF_API int ff_scene_file_load(const char* path, FfSceneFile** out_scene);
+FF_API const FfGeometry* ff_scene_file_geometries(const FfSceneFile* scene, int* out_count);
+/* Camera of the file for a width x height image (UpdateBasisAxis applied). */
+FF_API int ff_scene_file_camera(const FfSceneFile* scene, int width, int height, FfCamera* out_camera);
+FF_API void ff_scene_file_free(FfSceneFile* scene);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

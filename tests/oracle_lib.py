@@ -80,7 +80,7 @@ def oracle_render(scene, camera, params, window=None, threads=8, want_counters=F
     rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
     rad = np.zeros((h, w, 3), dtype=np.float32)
     ctr = OrcCounters()
-    lib.orc_render(scene.geometries, len(scene.geometries), C.byref(camera), C.byref(params), x0, y0, w, h,
+    lib.orc_render(scene.geometries, len(scene), C.byref(camera), C.byref(params), x0, y0, w, h,
                    rgb8.ctypes.data, rad.ctypes.data, C.byref(ctr), threads)
     if want_counters:
         return rgb8, rad, ctr
@@ -99,6 +99,6 @@ def oracle_intersect(scene, origins, directions):
     for i in range(n):
         ray.m_origin = T.FfVec3(*o[i])
         ray.m_direction = T.FfVec3(*d[i])
-        lib.orc_intersect_rays(C.byref(ray), scene.geometries, len(scene.geometries), C.byref(isect))
+        lib.orc_intersect_rays(C.byref(ray), scene.geometries, len(scene), C.byref(isect))
         out[i] = np.frombuffer(bytes(isect), dtype=INTERSECT_DTYPE, count=1)[0]
     return out

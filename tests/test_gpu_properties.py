@@ -204,3 +204,29 @@ def test_non_unit_and_degenerate_rays(tracer):
         assert np.array_equal(got["geom"][h], exp["geom"][h]) and np.array_equal(got["tri"][h], exp["tri"][h])
         assert np.array_equal(got["t"][h].view(np.uint32), exp["t"][h].view(np.uint32))
         assert np.array_equal(got["point"][h].view(np.uint32), exp["point"][h].view(np.uint32))
+
+
+def test_gl_interop_reports_unavailable_on_a_headless_box(tracer):
+    """ff_register_gl_pbo (utilities.h:618 twin) without a current GL context: a status code, not a crash."""
+    import ctypes as C
+    l = lib.load()
+    st = C.c_void_p()
+    assert l.ff_create(C.byref(st), 0) == T.FF_OK
+    assert l.ff_register_gl_pbo(st, 1, 64, 64) == T.FF_ERR_GL_UNAVAILABLE
+    assert b"hipGraphicsGLRegisterBuffer" in l.ff_last_error()
+    cam = scenes.default_camera(64, 64)
+    params = lib.render_params(64, 64)
+    assert l.ff_render_to_pbo(st, C.byref(cam), C.byref(params)) == T.FF_ERR_GL_UNAVAILABLE
+    assert l.ff_unregister_gl_pbo(st) == T.FF_OK
+    l.ff_destroy(st)
+
+
+def test_scene_file_renders_like_the_oracle(tracer):
+    import os
+    sf = lib.SceneFile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "box.scene"))
+    cam = sf.camera(120, 90)
+    tracer.upload_scene(sf)
+    params = lib.render_params(120, 90, 4, 3)
+    rgb8, rad = tracer.render(cam, params)
+    exp8, exprad = oracle_render(sf, cam, params, threads=8)
+    assert np.array_equal(rgb8, exp8) and np.array_equal(rad.view(np.uint32), exprad.view(np.uint32)) and exprad.max() > 0
