@@ -40,6 +40,10 @@ struct FfState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
+    int scheduler = 0;      // 0 = time-sliced kernel, 1 = path-pool kernel (FF_SCHEDULER=pool)
+    int pool_slots = 192, pool_refill = 16, pool_low = 24;
+    unsigned* d_pool = nullptr;
+    size_t pool_bytes = 0;
     int setup_threshold = 14, leaf_threshold = 16; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
@@ -159,7 +163,9 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.nodes = s->d_nodes;
     const int block_threads = prm->trace_mode == FF_TRACE_BVH ? s->block_threads : kBlockThreads;
     k.stack_depth = s->max_depth + 1; // at most one pending sibling per level above the cursor, plus one spare slot
-    const int fit = max_lds_nodes(k.stack_depth, block_threads, s->num_geoms);
+    const bool use_pool = prm->trace_mode == FF_TRACE_BVH && s->scheduler == 1;
+    int fit = max_lds_nodes(k.stack_depth, use_pool ? 1024 : block_threads, s->num_geoms);
+    if (use_pool) fit -= (int)((pool_list_bytes(s->pool_slots, 1024) + sizeof(BvhNode) - 1) / sizeof(BvhNode));
     k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;
     if (k.lds_nodes < 0) k.lds_nodes = 0;
     k.accum = s->d_accum;
@@ -174,6 +180,15 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
 
+    if (use_pool) {
+        const size_t need = pool_workspace_bytes(s->pool_slots, grid, 1024);
+        int pst = ensure_bytes((void**)&s->d_pool, &s->pool_bytes, need);
+        if (pst != FF_OK) return pst;
+        k.pool = s->d_pool;
+        k.pool_slots = s->pool_slots;
+        k.pool_refill = s->pool_refill;
+        k.pool_low = s->pool_low;
+    }
     hipStream_t st = s->stream;
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced and missed pixels read 0
     if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
@@ -231,6 +246,10 @@ int ff_create(FfState** out_state, int device_id)
         if (v == 512 || v == 768 || v == 1024) s->block_threads = v;
     }
     if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) s->setup_threshold = std::max(0, std::min(1 << 14, std::atoi(e)));
+    if (const char* e = std::getenv("FF_SCHEDULER")) s->scheduler = std::strcmp(e, "pool") == 0 ? 1 : 0;
+    if (const char* e = std::getenv("FF_POOL_SLOTS")) s->pool_slots = std::max(64, std::min(1024, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_REFILL")) s->pool_refill = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_LOW")) s->pool_low = std::max(1, std::min(65, std::atoi(e)));
     if (const char* e = std::getenv("FF_LEAF_THRESHOLD")) s->leaf_threshold = std::max(1, std::min(64, std::atoi(e)));
     hipError_t pe = prepare_kernels();
     if (pe != hipSuccess) {
@@ -253,6 +272,7 @@ int ff_destroy(FfState* s)
     if (s->pbo_resource) (void)hipGraphicsUnregisterResource(s->pbo_resource);
     free_scene(s);
     if (s->d_accum) (void)hipFree(s->d_accum);
+    if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_rgb8) (void)hipFree(s->d_rgb8);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_queue) (void)hipFree(s->d_queue);

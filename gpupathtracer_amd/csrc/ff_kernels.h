@@ -34,6 +34,11 @@ struct KParams {
     // BVH kernel scheduling knobs: setup_threshold = traversal time slice in inner-node rounds (0 = run every query to
     // completion before the wave shades); leaf_threshold = number of lanes holding a leaf that ends an inner-node phase early
     int setup_threshold, leaf_threshold;
+    // path-pool scheduler (null pool = time-sliced kernel): wave-private workspace of pool_slots x 24 words per wave;
+    // pool_refill = idle lanes that trigger a refill from the READY list; pool_low = running lanes below which a partial
+    // batch of FINISHED slots is set up although fewer than 64 are waiting
+    unsigned* pool;
+    int pool_slots, pool_refill, pool_low;
     // scene
     int num_geoms;
     int num_planes;  // records [0, num_planes) are planes, the rest meshes (processing order)
@@ -67,6 +72,8 @@ struct RayBatchParams {
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms);
 // Largest node count that fits LDS next to a stack of `stack_depth` entries per lane.
 int max_lds_nodes(int stack_depth, int block_threads, int num_geoms);
+size_t pool_list_bytes(int pool_slots, int block_threads);
+size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads);
 
 // block_threads: 512 or 1024 for the BVH kernel; the brute-force kernel always runs 512.
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream);

@@ -1120,6 +1120,189 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     flush_counters(p, lane, cnt, STATS);
 }
 
+// ---- the BVH mega-kernel with a wave-private path pool ---------------------------------------------------------------
+//
+// The time-sliced kernel above still runs its two halves at partial occupancy: after a slice only the finished lanes
+// shade (~50 %), and during a slice the finished lanes idle (~30 %).  Here every wave owns a POOL of P path slots
+// (P = 3 x 64) whose state lives in a wave-private global workspace (96 B per slot, slot-major so that 64 consecutive
+// slots are one coalesced access; it stays L2 / Infinity-Cache resident) and works in two kinds of steps:
+//
+//   S (setup)     64 lanes take 64 FINISHED slots: resolve the hit exactly, shade, spawn the next ray (or fetch a new
+//                 pixel), screen the planes and the mesh boxes, and file the slot as READY (needs BVH traversal) or
+//                 FINISHED again (planes only).  All lanes busy.
+//   T (traverse)  lanes run BVH traversal for the slot they hold; a lane whose query completes writes the outcome to
+//                 its slot, files it as FINISHED and immediately takes another READY slot, so the traversal loops stay
+//                 populated although per-ray traversal cost is heavy-tailed.  A lane in the middle of a long query
+//                 simply keeps its registers and LDS stack across S steps.
+//
+// The slot lists (READY / FINISHED) are wave-private arrays in LDS; only the owning wave touches its pool, so no atomics
+// or barriers are involved.  Results are unchanged: a slot owns its pixel for all samples (sequential accumulation), the
+// RNG is counter-based, and every hit is resolved with the exact reference arithmetic.
+
+enum PoolWord : int {
+    kRayO = 0, kRayD = 3, kBeta = 6, kAcc = 9, kLpix = 12, kGxy = 13, kSb = 14,
+    kPendDist = 15, kPendGeom = 16, kPendRec = 17, kMeshes = 18, kBestDist = 19, kBestGeom = 20, kBestRec = 21, kFlags = 22,
+    kPoolWords = 24
+};
+constexpr unsigned kSlotHasQuery = 1u, kSlotAlive = 2u;
+
+struct Pool {
+    unsigned* base; // this wave's workspace: word k of slot j at base[k * slots + j]
+    int slots;
+};
+__device__ __forceinline__ float pool_f(const Pool& W, int j, int k) { return __uint_as_float(W.base[k * W.slots + j]); }
+__device__ __forceinline__ unsigned pool_u(const Pool& W, int j, int k) { return W.base[k * W.slots + j]; }
+__device__ __forceinline__ void pool_set_f(const Pool& W, int j, int k, float v) { W.base[k * W.slots + j] = __float_as_uint(v); }
+__device__ __forceinline__ void pool_set_u(const Pool& W, int j, int k, unsigned v) { W.base[k * W.slots + j] = v; }
+
+template <bool STATS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
+    stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
+
+    const int P = p.pool_slots;
+    Pool W;
+    W.slots = P;
+    W.base = p.pool + ((size_t)blockIdx.x * (BLOCK / kWave) + (size_t)wave) * (size_t)P * kPoolWords;
+    // wave-private slot lists in LDS, after the geometry records: READY then FINISHED, 16-bit slot ids
+    unsigned short* lists = reinterpret_cast<unsigned short*>(ff_smem + L.geom_base + p.num_geoms * kGeomVec4) + (size_t)wave * 2 * P;
+    unsigned short* ready = lists;
+    unsigned short* finished = lists + P;
+    for (int j = lane; j < P; j += kWave) {
+        finished[j] = (unsigned short)j;
+        pool_set_u(W, j, kFlags, 0u);
+    }
+    int n_ready = 0, n_finished = P; // wave-uniform
+
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int my_slot = -1; // slot whose query this lane is traversing
+    Ray ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    Segment S;
+    S.best = { kInf, -1, -1 };
+    S.pend = { kInf, -1, -1 };
+    S.meshes = 0u;
+    S.cur = kDone; S.sp = 0; S.mesh = -1; S.resume = 0;
+    S.osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
+    S.scale = 1.f;
+
+    for (int guard = 0; guard < (1 << 28); ++guard) {
+        const int running = __popcll(__ballot(my_slot >= 0));
+        // ---- S step: a full batch of finished slots is waiting, or nothing else can make progress -----------------------
+        if (n_finished >= kWave || (n_finished > 0 && n_ready == 0 && running < p.pool_low)) {
+            const int n = n_finished < kWave ? n_finished : kWave;
+            n_finished -= n;
+            bool to_ready = false, to_finished = false;
+            int j = 0;
+            if (lane < n) {
+                j = finished[n_finished + lane];
+                const unsigned flags = pool_u(W, j, kFlags);
+                Path Q;
+                init_path(Q);
+                bool alive = (flags & kSlotAlive) != 0u;
+                if (alive) {
+                    Q.ray.ox = pool_f(W, j, kRayO); Q.ray.oy = pool_f(W, j, kRayO + 1); Q.ray.oz = pool_f(W, j, kRayO + 2);
+                    Q.ray.dx = pool_f(W, j, kRayD); Q.ray.dy = pool_f(W, j, kRayD + 1); Q.ray.dz = pool_f(W, j, kRayD + 2);
+                    Q.bx = pool_f(W, j, kBeta); Q.by = pool_f(W, j, kBeta + 1); Q.bz = pool_f(W, j, kBeta + 2);
+                    Q.ax = pool_f(W, j, kAcc); Q.ay = pool_f(W, j, kAcc + 1); Q.az = pool_f(W, j, kAcc + 2);
+                    Q.lpix = (int)pool_u(W, j, kLpix);
+                    Q.gxy = pool_u(W, j, kGxy);
+                    const unsigned sb = pool_u(W, j, kSb);
+                    Q.s = (int)(sb & 0xFFFFFFu);
+                    Q.b = (int)(sb >> 24);
+                }
+                if (alive && (flags & kSlotHasQuery) != 0u) {
+                    Segment R;
+                    R.best.dist = pool_f(W, j, kBestDist); R.best.geom = (int)pool_u(W, j, kBestGeom); R.best.rec = (int)pool_u(W, j, kBestRec);
+                    R.pend.dist = pool_f(W, j, kPendDist); R.pend.geom = (int)pool_u(W, j, kPendGeom); R.pend.rec = (int)pool_u(W, j, kPendRec);
+                    Best best;
+                    finish_segment(L, p.tris, Q.ray, R, best);
+                    const bool hit = best.geom >= 0;
+                    MaterialRef M;
+                    M.global = nullptr;
+                    M.lds = L;
+                    M.g = best.geom;
+                    alive = shade_and_advance(p, best, hit, M, Q);
+                }
+                if (!alive) alive = acquire_pixel(p, lane, Q);
+                if (alive) {
+                    Segment R;
+                    if (STATS) probe_round(cnt.segment_rounds);
+                    begin_segment<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, Q.ray, R, cnt);
+                    cnt.rays += 1;
+                    pool_set_f(W, j, kRayO, Q.ray.ox); pool_set_f(W, j, kRayO + 1, Q.ray.oy); pool_set_f(W, j, kRayO + 2, Q.ray.oz);
+                    pool_set_f(W, j, kRayD, Q.ray.dx); pool_set_f(W, j, kRayD + 1, Q.ray.dy); pool_set_f(W, j, kRayD + 2, Q.ray.dz);
+                    pool_set_f(W, j, kBeta, Q.bx); pool_set_f(W, j, kBeta + 1, Q.by); pool_set_f(W, j, kBeta + 2, Q.bz);
+                    pool_set_f(W, j, kAcc, Q.ax); pool_set_f(W, j, kAcc + 1, Q.ay); pool_set_f(W, j, kAcc + 2, Q.az);
+                    pool_set_u(W, j, kLpix, (unsigned)Q.lpix);
+                    pool_set_u(W, j, kGxy, Q.gxy);
+                    pool_set_u(W, j, kSb, (unsigned)Q.s | ((unsigned)Q.b << 24));
+                    pool_set_f(W, j, kPendDist, R.pend.dist); pool_set_u(W, j, kPendGeom, (unsigned)R.pend.geom); pool_set_u(W, j, kPendRec, (unsigned)R.pend.rec);
+                    pool_set_f(W, j, kBestDist, R.best.dist); pool_set_u(W, j, kBestGeom, (unsigned)R.best.geom); pool_set_u(W, j, kBestRec, (unsigned)R.best.rec);
+                    pool_set_u(W, j, kMeshes, R.meshes);
+                    pool_set_u(W, j, kFlags, kSlotHasQuery | kSlotAlive);
+                    to_ready = R.meshes != 0u;
+                    to_finished = !to_ready;
+                } else {
+                    pool_set_u(W, j, kFlags, 0u); // queue drained: the slot retires
+                }
+            }
+            // file the slots (wave-wide prefix compaction into the LDS lists)
+            const unsigned long long m_r = __ballot(to_ready), m_f = __ballot(to_finished);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (to_ready) ready[n_ready + __popcll(m_r & below)] = (unsigned short)j;
+            if (to_finished) finished[n_finished + __popcll(m_f & below)] = (unsigned short)j;
+            n_ready += __popcll(m_r);
+            n_finished += __popcll(m_f);
+            continue;
+        }
+        if (running == 0 && n_ready == 0) break; // n_finished == 0 here: every slot has retired
+
+        // ---- T step: refill idle lanes, traverse a slice, retire completed queries ------------------------------------
+        {
+            const bool idle = my_slot < 0;
+            const unsigned long long m_idle = __ballot(idle);
+            const int n_idle = __popcll(m_idle);
+            if (n_ready > 0 && (n_idle >= p.pool_refill || running == 0)) {
+                const int k = __popcll(m_idle & ((1ull << lane) - 1ull));
+                if (idle && k < n_ready) {
+                    const int j = ready[n_ready - 1 - k];
+                    my_slot = j;
+                    ray.ox = pool_f(W, j, kRayO); ray.oy = pool_f(W, j, kRayO + 1); ray.oz = pool_f(W, j, kRayO + 2);
+                    ray.dx = pool_f(W, j, kRayD); ray.dy = pool_f(W, j, kRayD + 1); ray.dz = pool_f(W, j, kRayD + 2);
+                    S.best.dist = pool_f(W, j, kBestDist); S.best.geom = (int)pool_u(W, j, kBestGeom); S.best.rec = (int)pool_u(W, j, kBestRec);
+                    S.pend.dist = pool_f(W, j, kPendDist); S.pend.geom = (int)pool_u(W, j, kPendGeom); S.pend.rec = (int)pool_u(W, j, kPendRec);
+                    S.meshes = pool_u(W, j, kMeshes);
+                    S.cur = kDone; S.sp = 0; S.mesh = -1; S.resume = 0;
+                }
+                n_ready -= n_idle < n_ready ? n_idle : n_ready;
+            }
+        }
+        if (my_slot >= 0) {
+            traverse_budget<STATS>(L, p.tris, p.nodes, ray, S, cnt, p.setup_threshold, p.leaf_threshold);
+            if (segment_done(S)) {
+                const int j = my_slot;
+                pool_set_f(W, j, kBestDist, S.best.dist); pool_set_u(W, j, kBestGeom, (unsigned)S.best.geom); pool_set_u(W, j, kBestRec, (unsigned)S.best.rec);
+                pool_set_f(W, j, kPendDist, S.pend.dist); pool_set_u(W, j, kPendGeom, (unsigned)S.pend.geom); pool_set_u(W, j, kPendRec, (unsigned)S.pend.rec);
+            }
+        }
+        {
+            const bool done = my_slot >= 0 && segment_done(S);
+            const unsigned long long m_done = __ballot(done);
+            if (done) {
+                finished[n_finished + __popcll(m_done & ((1ull << lane) - 1ull))] = (unsigned short)my_slot;
+                my_slot = -1;
+            }
+            n_finished += __popcll(m_done);
+        }
+    }
+    flush_counters(p, lane, cnt, STATS);
+}
+
 // ---- the brute-force mega-kernel (reference loop, validation path) ---------------------------------------------------
 
 template <bool STATS>
@@ -1233,6 +1416,13 @@ size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_
            (size_t)num_geoms * sizeof(GeomRecord);
 }
 
+size_t pool_list_bytes(int pool_slots, int block_threads) { return (size_t)(block_threads / 64) * 2 * (size_t)pool_slots * sizeof(unsigned short); }
+
+size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads)
+{
+    return (size_t)grid_blocks * (size_t)(block_threads / 64) * (size_t)pool_slots * 24 * sizeof(unsigned);
+}
+
 int max_lds_nodes(int stack_depth, int block_threads, int num_geoms)
 {
     const long avail = (long)kLdsBudgetBytes - (long)stack_depth * (long)block_threads * (long)sizeof(unsigned) -
@@ -1254,6 +1444,8 @@ hipError_t prepare_kernels()
     FF_SET_LDS((trace_bvh_kernel<true, 768>))
     FF_SET_LDS((trace_bvh_kernel<false, 1024>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024>))
+    FF_SET_LDS((trace_pool_kernel<false, 1024>))
+    FF_SET_LDS((trace_pool_kernel<true, 1024>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
 #undef FF_SET_LDS
     return hipSuccess;
@@ -1263,8 +1455,14 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
 {
     const dim3 grid(grid_blocks);
     if (trace_mode == FF_TRACE_BVH) {
-        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
         const dim3 block(block_threads);
+        if (p.pool != nullptr) {
+            const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, 1024, p.num_geoms) + pool_list_bytes(p.pool_slots, 1024);
+            if (collect_stats) hipLaunchKernelGGL((trace_pool_kernel<true, 1024>), grid, dim3(1024), lds, stream, p);
+            else hipLaunchKernelGGL((trace_pool_kernel<false, 1024>), grid, dim3(1024), lds, stream, p);
+            return hipGetLastError();
+        }
+        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
         if (block_threads == 1024) {
             if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 1024>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((trace_bvh_kernel<false, 1024>), grid, block, lds, stream, p);

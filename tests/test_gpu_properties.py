@@ -230,3 +230,21 @@ def test_scene_file_renders_like_the_oracle(tracer):
     rgb8, rad = tracer.render(cam, params)
     exp8, exprad = oracle_render(sf, cam, params, threads=8)
     assert np.array_equal(rgb8, exp8) and np.array_equal(rad.view(np.uint32), exprad.view(np.uint32)) and exprad.max() > 0
+
+
+def test_pool_scheduler_is_bit_identical(monkeypatch):
+    """The experimental wave-private path-pool scheduler (FF_SCHEDULER=pool) must not change a single bit."""
+    scene = scenes.cornell_wahoo_scene()
+    cam = _inside(480, 270)
+    params = lib.render_params(480, 270, 8, 6, seed=99)
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        ref8, refr = t.render(cam, params)
+        rays = t.stats().rays_traced
+    monkeypatch.setenv("FF_SCHEDULER", "pool")
+    monkeypatch.setenv("FF_POOL_SLOTS", "128")
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        got8, gotr = t.render(cam, params)
+        assert t.stats().rays_traced == rays
+    assert np.array_equal(got8, ref8) and np.array_equal(gotr.view(np.uint32), refr.view(np.uint32))
