@@ -45,10 +45,13 @@ def parse_args():
     return ap.parse_args()
 
 
-def algorithmic_bytes(st, width, rows, launches):
+def algorithmic_bytes(st, width, rows, spp):
     """sum over rays of (node bytes x nodes visited + triangle bytes x triangles tested + ray) plus
-    the framebuffer (float4 accumulate per extra launch, float3 radiance + rgb8 out)."""
-    fb = (12 + 3) * width * rows + 32 * width * rows * max(0, launches - 1)
+    the framebuffer: one float4 per pixel and sample block written by the trace kernel and read by the combine pass,
+    float3 radiance + rgb8 out."""
+    block_spp = 64 * ((spp + 1023) // 1024)
+    blocks = (spp + block_spp - 1) // block_spp
+    fb = (12 + 3 + 32 * blocks) * width * rows
     return st.rays_traced * RAY_BYTES + st.nodes_visited * NODE_BYTES + st.tris_tested * TRI_BYTES + fb
 
 
@@ -119,7 +122,7 @@ def main():
     tracer.upload_scene(scene)
     tracer.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    strip_rows = ffdist.STRIP_ROWS if world > 1 else args.height
+    strip_rows = ffdist.strip_rows_for(world) if world > 1 else args.height
     local_rows = tracer.strips_local_rows(args.height, strip_rows, rank, world)
     rgb8 = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.uint8, device=device)
     rad = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.float32, device=device)
@@ -180,7 +183,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays / elapsed / 1e6
         # roofline of the dominant kernel (trace_kernel) on this rank: algorithmic bytes per launch / mean launch duration
-        algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, counted.kernel_launches) / max(1, counted.kernel_launches)
+        algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, args.spp) / max(1, counted.kernel_launches)
         mean_launch_s = kernel_ms / max(1, launches) / 1e3
         achieved = algo_bytes_launch / mean_launch_s / 1e9
         out = {
@@ -196,7 +199,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "trace_kernel<BVH>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
+                "kernel": "trace_bvh_kernel<false,1024>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
                 "algorithmic_bytes_per_launch": int(algo_bytes_launch),
                 "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
                             "tris": round(counted.tris_tested / max(1, counted.rays_traced), 3)},

@@ -112,13 +112,14 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     const bool debug = prm->shade_mode == FF_SHADE_NORMAL_DEBUG;
     const int spp = debug ? 1 : prm->spp;
     const int bounces = debug ? 1 : prm->bounces;
-    int chunk = (prm->spp_per_launch > 0 && !debug) ? prm->spp_per_launch : spp;
-    if (chunk > spp) chunk = spp;
-    const int launches = (spp + chunk - 1) / chunk;
-    if (launches > 1) {
-        int st = ensure_bytes((void**)&s->d_accum, &s->accum_bytes, local_pixels * 4 * sizeof(float));
-        if (st != FF_OK) return st;
-    }
+    // Samples are accumulated in blocks (a multiple of 64, at most 16 blocks per pixel up to 1024 spp and beyond): a
+    // block sums its samples sequentially, the combine kernel adds a pixel's blocks in order.  (pixel, block) is the unit
+    // of work, which keeps the persistent lanes balanced at the end of a frame and when a frame is split over GPUs.
+    const int block_spp = 64 * ((spp + 1023) / 1024);
+    const int num_blocks = (spp + block_spp - 1) / block_spp;
+    int blocks_per_launch = num_blocks;
+    if (prm->spp_per_launch > 0 && !debug) blocks_per_launch = std::max(1, (prm->spp_per_launch + block_spp - 1) / block_spp);
+    const int launches = (num_blocks + blocks_per_launch - 1) / blocks_per_launch;
 
     KParams k;
     std::memset(&k, 0, sizeof k);
@@ -148,10 +149,17 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.local_rows = local_rows;
     k.tiles_per_row = (W + 7) / 8;
     const uint64_t tiles = (uint64_t)k.tiles_per_row * (uint64_t)((local_rows + 7) / 8);
-    if (tiles * 64 >= (1ull << 32)) return fail(FF_ERR_INVALID_ARG, "image too large for the work queue");
-    k.total_items = (unsigned)(tiles * 64);
+    if (tiles * 64 * (uint64_t)num_blocks >= (1ull << 31)) return fail(FF_ERR_INVALID_ARG, "image too large for the work queue");
+    k.pix_items = (unsigned)(tiles * 64);
     k.bounces = bounces;
     k.spp_total = spp;
+    k.block_spp = block_spp;
+    k.num_blocks = num_blocks;
+    {
+        int bst = ensure_bytes((void**)&s->d_accum, &s->accum_bytes, (size_t)k.pix_items * (size_t)num_blocks * 4 * sizeof(float));
+        if (bst != FF_OK) return bst;
+    }
+    k.blocksums = reinterpret_cast<float4*>(s->d_accum);
     k.key = (unsigned)prm->seed ^ (unsigned)(prm->seed >> 32);
     k.shade_mode = prm->shade_mode;
     k.setup_threshold = s->setup_threshold;
@@ -168,7 +176,6 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     if (use_pool) fit -= (int)((pool_list_bytes(s->pool_slots, 1024) + sizeof(BvhNode) - 1) / sizeof(BvhNode));
     k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;
     if (k.lds_nodes < 0) k.lds_nodes = 0;
-    k.accum = s->d_accum;
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
@@ -176,7 +183,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
 
     const int blocks_per_cu = prm->trace_mode == FF_TRACE_BVH ? 1 : 2;
     int grid = s->num_cus * blocks_per_cu;
-    const uint64_t max_useful = (k.total_items + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
+    const uint64_t max_useful = ((uint64_t)k.pix_items * (uint64_t)num_blocks + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
 
@@ -196,13 +203,13 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     FF_HIP(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), st));
     FF_HIP(hipEventRecord(s->ev_begin, st));
     for (int l = 0; l < launches; ++l) {
-        k.spp_begin = l * chunk;
-        k.spp_end = (l + 1) * chunk < spp ? (l + 1) * chunk : spp;
-        k.first_chunk = l == 0;
-        k.last_chunk = l == launches - 1;
+        k.block_begin = l * blocks_per_launch;
+        k.block_end = std::min(num_blocks, (l + 1) * blocks_per_launch);
+        k.total_items = k.pix_items * (unsigned)(k.block_end - k.block_begin);
         FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
         FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st));
     }
+    FF_HIP(launch_combine(k, st));
     FF_HIP(hipEventRecord(s->ev_end, st));
     FF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;

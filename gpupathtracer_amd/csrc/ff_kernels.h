@@ -24,13 +24,15 @@ struct KParams {
     int xlim, ylim;    // pixels with x >= xlim or y >= ylim are not traced (FF_GRID_REFERENCE_FLOOR)
     // work decomposition: local rows of this part, in strips
     int strip_rows, part, num_parts, local_rows;
-    unsigned total_items; // number of work items (64 per 8x8 pixel tile of the local image)
+    unsigned total_items; // work items of this launch: pix_items x (block_end - block_begin)
+    unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
     // integrator
-    int bounces, spp_begin, spp_end, spp_total;
+    // samples are accumulated in blocks of block_spp (a block sums its samples sequentially from 0; the blocks of a pixel
+    // are summed in order by the combine kernel), which makes (pixel, block) an independent work item
+    int bounces, spp_total, block_spp, block_begin, block_end, num_blocks;
     unsigned key;       // Philox key (seed folded to 32 bits)
     int shade_mode;
-    int first_chunk, last_chunk;
     // BVH kernel scheduling knobs: setup_threshold = traversal time slice in inner-node rounds (0 = run every query to
     // completion before the wave shades); leaf_threshold = number of lanes holding a leaf that ends an inner-node phase early
     int setup_threshold, leaf_threshold;
@@ -48,7 +50,7 @@ struct KParams {
     int lds_nodes;   // nodes [0, lds_nodes) are staged in LDS
     int stack_depth; // entries per lane in the LDS traversal stack
     // outputs (local image: local_rows x width)
-    float* accum;            // float4 per local pixel: running radiance sum across spp chunks
+    float4* blocksums;       // [num_blocks][pix_items] radiance sums of the sample blocks (tile-major pixel order)
     unsigned char* rgb8;     // 3 bytes per local pixel, or null
     float* radiance;         // 3 floats per local pixel, or null
     unsigned* queue;         // work-item counter (zeroed before each launch)
@@ -77,6 +79,8 @@ size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads);
 
 // block_threads: 512 or 1024 for the BVH kernel; the brute-force kernel always runs 512.
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream);
+// Sums every pixel's sample blocks in order, scales by 1/spp and writes radiance / rgb8 (row-major, coalesced).
+hipError_t launch_combine(const KParams& p, hipStream_t stream);
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream);
 hipError_t launch_deinterleave(const void* src, void* dst, int width, int height, int strip_rows, int num_parts, int elem_bytes,
                                hipStream_t stream);

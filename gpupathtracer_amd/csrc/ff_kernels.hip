@@ -836,7 +836,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 
 // Per-lane path state.
 struct Path {
-    int lpix;      // local pixel index (row-major in the local image)
+    int bitem;     // where this (pixel, sample block)'s sum goes: block * pix_items + tile-major pixel item
+    int send;      // one past the last sample of the block
     unsigned gxy;  // global pixel coordinates x | y << 16; the RNG counter is the pixel index y*W+x (kernel.cu:191)
     int s, b;      // current sample / segment
     Ray ray;       // current world-space ray
@@ -890,23 +891,22 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
             if (item >= p.total_items) {
                 exhausted = true;
             } else {
-                // items walk 8x8 pixel tiles of the local image; padding items and untraced pixels are consumed and skipped
-                const int tile = (int)(item >> 6), in = (int)(item & 63u);
+                // an item is one sample block of one pixel; pixels walk 8x8 tiles of the local image (padding items and
+                // untraced pixels are consumed and skipped), blocks are the slow index
+                const unsigned blk = item / p.pix_items, pitem = item - blk * p.pix_items;
+                const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
                 const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
                 const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
                 const int strip = ly / p.strip_rows;
                 const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
                 if (lx < p.xlim && ly < p.local_rows && gy < p.ylim) {
                     got = true;
-                    P.lpix = ly * p.width + lx;
+                    const int block = p.block_begin + (int)blk;
+                    P.bitem = block * (int)p.pix_items + (int)pitem;
                     P.gxy = (unsigned)lx | ((unsigned)gy << 16);
-                    P.s = p.spp_begin;
-                    if (p.first_chunk) {
-                        P.ax = P.ay = P.az = 0.f;
-                    } else {
-                        const float4 prev = reinterpret_cast<const float4*>(p.accum)[P.lpix];
-                        P.ax = prev.x; P.ay = prev.y; P.az = prev.z;
-                    }
+                    P.s = block * p.block_spp;
+                    P.send = min(p.spp_total, P.s + p.block_spp);
+                    P.ax = P.ay = P.az = 0.f;
                     start_sample(p, P);
                 }
             }
@@ -977,32 +977,12 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
     P.ay = P.ay + Ly;
     P.az = P.az + Lz;
     ++P.s;
-    if (P.s < p.spp_end && !debug_shade) {
+    if (P.s < P.send && !debug_shade) {
         start_sample(p, P);
         return true;
     }
-    // pixel finished for this launch
-    if (p.last_chunk) {
-        float rx, ry, rz;
-        if (debug_shade) {
-            rx = P.ax; ry = P.ay; rz = P.az;
-        } else {
-            const float inv = 1.0f / (float)p.spp_total;
-            rx = P.ax * inv; ry = P.ay * inv; rz = P.az * inv;
-        }
-        if (p.radiance) {
-            p.radiance[3 * (size_t)P.lpix] = rx;
-            p.radiance[3 * (size_t)P.lpix + 1] = ry;
-            p.radiance[3 * (size_t)P.lpix + 2] = rz;
-        }
-        if (p.rgb8) {
-            p.rgb8[3 * (size_t)P.lpix] = to_u8(rx);
-            p.rgb8[3 * (size_t)P.lpix + 1] = to_u8(ry);
-            p.rgb8[3 * (size_t)P.lpix + 2] = to_u8(rz);
-        }
-    } else {
-        reinterpret_cast<float4*>(p.accum)[P.lpix] = make_float4(P.ax, P.ay, P.az, 0.f);
-    }
+    // sample block finished: its sum goes to the block buffer (the combine kernel adds a pixel's blocks in order)
+    p.blocksums[P.bitem] = make_float4(P.ax, P.ay, P.az, 0.f);
     return false;
 }
 
@@ -1033,7 +1013,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
 
 __device__ __forceinline__ void init_path(Path& P)
 {
-    P.lpix = 0; P.gxy = 0; P.s = 0; P.b = 0;
+    P.bitem = 0; P.send = 0; P.gxy = 0; P.s = 0; P.b = 0;
     P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     P.bx = P.by = P.bz = 1.f;
     P.ax = P.ay = P.az = 0.f;
@@ -1140,8 +1120,8 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 // RNG is counter-based, and every hit is resolved with the exact reference arithmetic.
 
 enum PoolWord : int {
-    kRayO = 0, kRayD = 3, kBeta = 6, kAcc = 9, kLpix = 12, kGxy = 13, kSb = 14,
-    kPendDist = 15, kPendGeom = 16, kPendRec = 17, kMeshes = 18, kBestDist = 19, kBestGeom = 20, kBestRec = 21, kFlags = 22,
+    kRayO = 0, kRayD = 3, kBeta = 6, kAcc = 9, kBitem = 12, kGxy = 13, kSb = 14,
+    kPendDist = 15, kPendGeom = 16, kPendRec = 17, kMeshes = 18, kBestDist = 19, kBestGeom = 20, kBestRec = 21, kFlags = 22, kSend = 23,
     kPoolWords = 24
 };
 constexpr unsigned kSlotHasQuery = 1u, kSlotAlive = 2u;
@@ -1209,7 +1189,8 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     Q.ray.dx = pool_f(W, j, kRayD); Q.ray.dy = pool_f(W, j, kRayD + 1); Q.ray.dz = pool_f(W, j, kRayD + 2);
                     Q.bx = pool_f(W, j, kBeta); Q.by = pool_f(W, j, kBeta + 1); Q.bz = pool_f(W, j, kBeta + 2);
                     Q.ax = pool_f(W, j, kAcc); Q.ay = pool_f(W, j, kAcc + 1); Q.az = pool_f(W, j, kAcc + 2);
-                    Q.lpix = (int)pool_u(W, j, kLpix);
+                    Q.bitem = (int)pool_u(W, j, kBitem);
+                    Q.send = (int)pool_u(W, j, kSend);
                     Q.gxy = pool_u(W, j, kGxy);
                     const unsigned sb = pool_u(W, j, kSb);
                     Q.s = (int)(sb & 0xFFFFFFu);
@@ -1238,7 +1219,8 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     pool_set_f(W, j, kRayD, Q.ray.dx); pool_set_f(W, j, kRayD + 1, Q.ray.dy); pool_set_f(W, j, kRayD + 2, Q.ray.dz);
                     pool_set_f(W, j, kBeta, Q.bx); pool_set_f(W, j, kBeta + 1, Q.by); pool_set_f(W, j, kBeta + 2, Q.bz);
                     pool_set_f(W, j, kAcc, Q.ax); pool_set_f(W, j, kAcc + 1, Q.ay); pool_set_f(W, j, kAcc + 2, Q.az);
-                    pool_set_u(W, j, kLpix, (unsigned)Q.lpix);
+                    pool_set_u(W, j, kBitem, (unsigned)Q.bitem);
+                    pool_set_u(W, j, kSend, (unsigned)Q.send);
                     pool_set_u(W, j, kGxy, Q.gxy);
                     pool_set_u(W, j, kSb, (unsigned)Q.s | ((unsigned)Q.b << 24));
                     pool_set_f(W, j, kPendDist, R.pend.dist); pool_set_u(W, j, kPendGeom, (unsigned)R.pend.geom); pool_set_u(W, j, kPendRec, (unsigned)R.pend.rec);
@@ -1383,6 +1365,42 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     p.out[i] = out;
 }
 
+// Final pass of a frame: add every pixel's sample-block sums in block order, scale by 1/spp (kernel.cu:214 stores the
+// colour as 8 bits; the float radiance is kept next to it), write rows coalesced.  Untraced pixels keep the cleared 0.
+__global__ void combine_kernel(const KParams p)
+{
+    const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ly = blockIdx.y;
+    if (lx >= p.width || ly >= p.local_rows) return;
+    const int strip = ly / p.strip_rows;
+    const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
+    if (lx >= p.xlim || gy >= p.ylim) return;
+    const unsigned pitem = (unsigned)(((ly >> 3) * p.tiles_per_row + (lx >> 3)) * 64 + ((ly & 7) * 8 + (lx & 7)));
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int b = 0; b < p.num_blocks; ++b) {
+        const float4 v = p.blocksums[(size_t)b * p.pix_items + pitem];
+        ax = ax + v.x;
+        ay = ay + v.y;
+        az = az + v.z;
+    }
+    float rx = ax, ry = ay, rz = az;
+    if (p.shade_mode != FF_SHADE_NORMAL_DEBUG) {
+        const float inv = 1.0f / (float)p.spp_total;
+        rx = ax * inv; ry = ay * inv; rz = az * inv;
+    }
+    const size_t lpix = (size_t)ly * (size_t)p.width + (size_t)lx;
+    if (p.radiance) {
+        p.radiance[3 * lpix] = rx;
+        p.radiance[3 * lpix + 1] = ry;
+        p.radiance[3 * lpix + 2] = rz;
+    }
+    if (p.rgb8) {
+        p.rgb8[3 * lpix] = to_u8(rx);
+        p.rgb8[3 * lpix + 1] = to_u8(ry);
+        p.rgb8[3 * lpix + 2] = to_u8(rz);
+    }
+}
+
 // Strip de-interleave after the framebuffer gather: src = parts' compact row blocks back to back, dst = image order.
 __global__ void deinterleave_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int width, int height,
                                     int strip_rows, int num_parts, int elem_bytes)
@@ -1479,6 +1497,14 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
         if (collect_stats) hipLaunchKernelGGL((trace_brute_kernel<true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((trace_brute_kernel<false>), grid, block, lds, stream, p);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_combine(const KParams& p, hipStream_t stream)
+{
+    if (p.width <= 0 || p.local_rows <= 0) return hipSuccess;
+    const dim3 block(256), grid((p.width + 255) / 256, p.local_rows);
+    hipLaunchKernelGGL(combine_kernel, grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -10,6 +10,12 @@ import numpy as np
 STRIP_ROWS = 16  # the reference's block height (kernel.cu:306); strips of 16 rows are dealt round-robin to ranks
 
 
+def strip_rows_for(world_size):
+    """Strip height used by the benchmark: 16 rows for 2 ranks, thinner strips for more ranks so that every rank gets the
+    same number of rows to within one strip (1080 rows over 8 ranks: 4-row strips -> 136 or 132 rows per rank)."""
+    return 16 if world_size <= 2 else (8 if world_size <= 4 else 4)
+
+
 def strip_layout(height, strip_rows, num_parts):
     """rows owned by each part, in part order (mirrors ff_strips_local_rows)."""
     nstrips = (height + strip_rows - 1) // strip_rows

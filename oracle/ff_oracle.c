@@ -622,8 +622,16 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
         return;
     }
 
+    /* Samples are accumulated in blocks: a block sums its samples sequentially from 0, the blocks of a pixel are added
+     * in order (block size: a multiple of 64, 64 up to 1024 spp).  The order is part of the result's definition. */
+    const int block_spp = 64 * ((p->spp + 1023) / 1024);
+    float total[3] = { 0.f, 0.f, 0.f };
     float acc[3] = { 0.f, 0.f, 0.f };
     for (int s = 0; s < p->spp; ++s) {
+        if (s > 0 && s % block_spp == 0) {
+            total[0] = total[0] + acc[0]; total[1] = total[1] + acc[1]; total[2] = total[2] + acc[2];
+            acc[0] = acc[1] = acc[2] = 0.f;
+        }
         FfRay ray = primary;
         float beta[3] = { 1.f, 1.f, 1.f };
         float L[3] = { 0.f, 0.f, 0.f };
@@ -686,10 +694,11 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
         acc[1] = acc[1] + L[1];
         acc[2] = acc[2] + L[2];
     }
+    total[0] = total[0] + acc[0]; total[1] = total[1] + acc[1]; total[2] = total[2] + acc[2];
     float inv = 1.0f / (float)p->spp;
-    rad3[0] = acc[0] * inv;
-    rad3[1] = acc[1] * inv;
-    rad3[2] = acc[2] * inv;
+    rad3[0] = total[0] * inv;
+    rad3[1] = total[1] * inv;
+    rad3[2] = total[2] * inv;
     *any_hit = 1;
 }
 

@@ -109,7 +109,8 @@ def test_intersect_rays_vs_oracle(tracer, scene_name, mode):
     assert (got["geom"][~h] == -1).all() and (got["t"][~h] == 0).all()
 
 
-@pytest.mark.parametrize("w,h,bounces,spp,seed", [(48, 32, 8, 3, 1234), (33, 17, 5, 2, 99), (8, 8, 2, 16, 5)])
+@pytest.mark.parametrize("w,h,bounces,spp,seed", [(48, 32, 8, 3, 1234), (33, 17, 5, 2, 99), (8, 8, 2, 16, 5),
+                                                  (16, 12, 4, 150, 7)])  # 150 spp = three sample blocks (64 + 64 + 22)
 def test_path_live_oracle(tracer, w, h, bounces, spp, seed):
     """Seeded live comparison (sizes the oracle finishes in seconds), including ragged image sizes."""
     scene = scenes.cornell_wahoo_scene()

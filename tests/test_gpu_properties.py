@@ -101,13 +101,14 @@ def test_spp_chunking_and_determinism(tracer):
     scene = scenes.cornell_wahoo_scene()
     cam = _inside(320, 180)
     tracer.upload_scene(scene)
-    one = tracer.render(cam, lib.render_params(320, 180, 8, 24))
-    again = tracer.render(cam, lib.render_params(320, 180, 8, 24))
-    chunks = tracer.render(cam, lib.render_params(320, 180, 8, 24, spp_per_launch=5))
-    assert tracer.stats().kernel_launches == 5
+    one = tracer.render(cam, lib.render_params(320, 180, 8, 200))
+    assert tracer.stats().kernel_launches == 1
+    again = tracer.render(cam, lib.render_params(320, 180, 8, 200))
+    chunks = tracer.render(cam, lib.render_params(320, 180, 8, 200, spp_per_launch=64))  # 200 spp = 4 sample blocks
+    assert tracer.stats().kernel_launches == 4
     for other in (again, chunks):
         assert np.array_equal(one[0], other[0]) and np.array_equal(one[1].view(np.uint32), other[1].view(np.uint32))
-    different_seed = tracer.render(cam, lib.render_params(320, 180, 8, 24, seed=1))
+    different_seed = tracer.render(cam, lib.render_params(320, 180, 8, 200, seed=1))
     assert not np.array_equal(one[1], different_seed[1])
 
 
