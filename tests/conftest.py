@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the in-tree artefacts if a fresh checkout has none (the .so files are git-ignored): the HIP library with
+    hipcc (cross-compiles without a GPU) and the CPU oracle with gcc.  Same recipe as __graft_entry__.build()."""
+    import subprocess
+    lib_so = os.path.join(ROOT, "gpupathtracer_amd", "libfirefly_hip.so")
+    if not os.path.exists(lib_so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gpupathtracer_amd", "csrc")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libff_oracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libff_oracle.so"])
+
+
 @pytest.fixture(scope="session")
 def ff():
     """The product library's ctypes binding (host-side functions work without a GPU)."""
