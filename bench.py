@@ -55,6 +55,26 @@ def algorithmic_bytes(st, width, rows, spp):
     return st.rays_traced * RAY_BYTES + st.nodes_visited * NODE_BYTES + st.tris_tested * TRI_BYTES + fb
 
 
+def measured_traffic(args, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC measurement (profiles/*_traffic.json, collected
+    with rocprofv3 --pmc in separate passes), when it was taken on exactly this workload; otherwise None."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not name.endswith("_traffic.json"):
+            continue
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                d = json.load(f)
+            w = d["workload"]
+            if (w["width"], w["height"], w["bounces"], w["spp"], w["n_gpus"], w["camera"], w["trace"]) == (
+                    args.width, args.height, args.bounces, args.spp, world, args.camera, args.trace_mode):
+                best = int(d["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
+
+
 def cpu_baseline(scene, camera, args):
     """The CPU oracle (a from-scratch port of the reference's brute-force loop; the reference has no CPU path) timed on
     a bounded window of the same workload on this box's host cores."""
@@ -198,7 +218,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, world),
                 "kernel": "trace_bvh_kernel<false,1024>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
                 "algorithmic_bytes_per_launch": int(algo_bytes_launch),
                 "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
