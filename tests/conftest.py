@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own HIP/HSA runtime.  Whichever HIP runtime is loaded first serves the whole process, and a
+# second one cannot open the GPU any more; tests that use torch on the GPU therefore need torch imported BEFORE
+# libfirefly_hip.so pulls in /opt/rocm's runtime (bench.py imports torch first for the same reason).
+try:
+    import torch  # noqa: F401
+except ImportError:  # the product itself does not need torch
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

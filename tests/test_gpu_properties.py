@@ -249,3 +249,25 @@ def test_pool_scheduler_is_bit_identical(monkeypatch):
         got8, gotr = t.render(cam, params)
         assert t.stats().rays_traced == rays
     assert np.array_equal(got8, ref8) and np.array_equal(gotr.view(np.uint32), refr.view(np.uint32))
+
+
+def test_c_example_through_the_abi(tracer, tmp_path):
+    """examples/headless_render.c: plain C against include/firefly/*.h + libfirefly_hip.so (no Python, no HIP headers)
+    produces the same framebuffer as the ctypes path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "headless_render")
+    libdir = os.path.join(root, "gpupathtracer_amd")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "headless_render.c"),
+                           "-L" + libdir, "-lfirefly_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    scene_path = os.path.join(root, "tests", "data", "box.scene")
+    out = str(tmp_path / "out.ppm")
+    subprocess.check_call([exe, scene_path, out, "96", "64", "3", "5"])
+    with open(out, "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"96 64\n" and f.readline() == b"255\n"
+        img = np.frombuffer(f.read(), dtype=np.uint8).reshape(64, 96, 3)
+    sf = lib.SceneFile(scene_path)
+    tracer.upload_scene(sf)
+    rgb8, _ = tracer.render(sf.camera(96, 64), lib.render_params(96, 64, 3, 5))
+    assert np.array_equal(img, rgb8) and img.any()
