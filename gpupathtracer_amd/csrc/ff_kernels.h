@@ -36,7 +36,7 @@ struct KParams {
     // BVH kernel scheduling knobs: setup_threshold = traversal time slice in inner-node rounds (0 = run every query to
     // completion before the wave shades); leaf_threshold = number of lanes holding a leaf that ends an inner-node phase early
     int setup_threshold, leaf_threshold;
-    // path-pool scheduler (null pool = time-sliced kernel): wave-private workspace of pool_slots x 24 words per wave;
+    // path-pool scheduler (null pool = time-sliced kernel): wave-private workspace of pool_slots x 28 words per wave;
     // pool_refill = idle lanes that trigger a refill from the READY list; pool_low = running lanes below which a partial
     // batch of FINISHED slots is set up although fewer than 64 are waiting
     unsigned* pool;

@@ -840,6 +840,7 @@ struct Path {
     int send;      // one past the last sample of the block
     unsigned gxy;  // global pixel coordinates x | y << 16; the RNG counter is the pixel index y*W+x (kernel.cu:191)
     int s, b;      // current sample / segment
+    float pdx, pdy, pdz; // primary direction of the pixel (every sample starts with the same ray: kernel.cu:200-205 has no jitter)
     Ray ray;       // current world-space ray
     float bx, by, bz; // throughput
     float ax, ay, az; // running sum over samples
@@ -868,7 +869,12 @@ __device__ __forceinline__ void primary_ray(const KParams& p, unsigned gxy, Ray&
 __device__ __forceinline__ void start_sample(const KParams& p, Path& P)
 {
     P.b = 0;
-    primary_ray(p, P.gxy, P.ray);
+    P.ray.ox = p.cam_pos[0];
+    P.ray.oy = p.cam_pos[1];
+    P.ray.oz = p.cam_pos[2];
+    P.ray.dx = P.pdx;
+    P.ray.dy = P.pdy;
+    P.ray.dz = P.pdz;
     P.bx = P.by = P.bz = 1.f;
 }
 
@@ -907,6 +913,10 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                     P.s = block * p.block_spp;
                     P.send = min(p.spp_total, P.s + p.block_spp);
                     P.ax = P.ay = P.az = 0.f;
+                    primary_ray(p, P.gxy, P.ray); // once per (pixel, block); its samples reuse the direction
+                    P.pdx = P.ray.dx;
+                    P.pdy = P.ray.dy;
+                    P.pdz = P.ray.dz;
                     start_sample(p, P);
                 }
             }
@@ -1014,6 +1024,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
 __device__ __forceinline__ void init_path(Path& P)
 {
     P.bitem = 0; P.send = 0; P.gxy = 0; P.s = 0; P.b = 0;
+    P.pdx = P.pdy = 0.f; P.pdz = 1.f;
     P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     P.bx = P.by = P.bz = 1.f;
     P.ax = P.ay = P.az = 0.f;
@@ -1104,7 +1115,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 //
 // The time-sliced kernel above still runs its two halves at partial occupancy: after a slice only the finished lanes
 // shade (~50 %), and during a slice the finished lanes idle (~30 %).  Here every wave owns a POOL of P path slots
-// (P = 3 x 64) whose state lives in a wave-private global workspace (96 B per slot, slot-major so that 64 consecutive
+// (P = 3 x 64) whose state lives in a wave-private global workspace (112 B per slot, slot-major so that 64 consecutive
 // slots are one coalesced access; it stays L2 / Infinity-Cache resident) and works in two kinds of steps:
 //
 //   S (setup)     64 lanes take 64 FINISHED slots: resolve the hit exactly, shade, spawn the next ray (or fetch a new
@@ -1121,8 +1132,8 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 
 enum PoolWord : int {
     kRayO = 0, kRayD = 3, kBeta = 6, kAcc = 9, kBitem = 12, kGxy = 13, kSb = 14,
-    kPendDist = 15, kPendGeom = 16, kPendRec = 17, kMeshes = 18, kBestDist = 19, kBestGeom = 20, kBestRec = 21, kFlags = 22, kSend = 23,
-    kPoolWords = 24
+    kPendDist = 15, kPendGeom = 16, kPendRec = 17, kMeshes = 18, kBestDist = 19, kBestGeom = 20, kBestRec = 21, kFlags = 22, kSend = 23, kPrimD = 24,
+    kPoolWords = 28
 };
 constexpr unsigned kSlotHasQuery = 1u, kSlotAlive = 2u;
 
@@ -1189,6 +1200,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     Q.ray.dx = pool_f(W, j, kRayD); Q.ray.dy = pool_f(W, j, kRayD + 1); Q.ray.dz = pool_f(W, j, kRayD + 2);
                     Q.bx = pool_f(W, j, kBeta); Q.by = pool_f(W, j, kBeta + 1); Q.bz = pool_f(W, j, kBeta + 2);
                     Q.ax = pool_f(W, j, kAcc); Q.ay = pool_f(W, j, kAcc + 1); Q.az = pool_f(W, j, kAcc + 2);
+                    Q.pdx = pool_f(W, j, kPrimD); Q.pdy = pool_f(W, j, kPrimD + 1); Q.pdz = pool_f(W, j, kPrimD + 2);
                     Q.bitem = (int)pool_u(W, j, kBitem);
                     Q.send = (int)pool_u(W, j, kSend);
                     Q.gxy = pool_u(W, j, kGxy);
@@ -1219,6 +1231,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     pool_set_f(W, j, kRayD, Q.ray.dx); pool_set_f(W, j, kRayD + 1, Q.ray.dy); pool_set_f(W, j, kRayD + 2, Q.ray.dz);
                     pool_set_f(W, j, kBeta, Q.bx); pool_set_f(W, j, kBeta + 1, Q.by); pool_set_f(W, j, kBeta + 2, Q.bz);
                     pool_set_f(W, j, kAcc, Q.ax); pool_set_f(W, j, kAcc + 1, Q.ay); pool_set_f(W, j, kAcc + 2, Q.az);
+                    pool_set_f(W, j, kPrimD, Q.pdx); pool_set_f(W, j, kPrimD + 1, Q.pdy); pool_set_f(W, j, kPrimD + 2, Q.pdz);
                     pool_set_u(W, j, kBitem, (unsigned)Q.bitem);
                     pool_set_u(W, j, kSend, (unsigned)Q.send);
                     pool_set_u(W, j, kGxy, Q.gxy);
@@ -1438,7 +1451,7 @@ size_t pool_list_bytes(int pool_slots, int block_threads) { return (size_t)(bloc
 
 size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads)
 {
-    return (size_t)grid_blocks * (size_t)(block_threads / 64) * (size_t)pool_slots * 24 * sizeof(unsigned);
+    return (size_t)grid_blocks * (size_t)(block_threads / 64) * (size_t)pool_slots * 28 * sizeof(unsigned);
 }
 
 int max_lds_nodes(int stack_depth, int block_threads, int num_geoms)
