@@ -29,8 +29,8 @@ struct FfState {
     uint64_t num_tris = 0;
     bool has_scene = false;
     // work buffers (device)
-    float* d_accum = nullptr;
-    size_t accum_bytes = 0;
+    float* d_blocksums = nullptr;
+    size_t blocksums_bytes = 0;
     unsigned char* d_rgb8 = nullptr;
     size_t rgb8_bytes = 0;
     float* d_radiance = nullptr;
@@ -156,10 +156,10 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.block_spp = block_spp;
     k.num_blocks = num_blocks;
     {
-        int bst = ensure_bytes((void**)&s->d_accum, &s->accum_bytes, (size_t)k.pix_items * (size_t)num_blocks * 4 * sizeof(float));
+        int bst = ensure_bytes((void**)&s->d_blocksums, &s->blocksums_bytes, (size_t)k.pix_items * (size_t)num_blocks * 4 * sizeof(float));
         if (bst != FF_OK) return bst;
     }
-    k.blocksums = reinterpret_cast<float4*>(s->d_accum);
+    k.blocksums = reinterpret_cast<float4*>(s->d_blocksums);
     k.key = (unsigned)prm->seed ^ (unsigned)(prm->seed >> 32);
     k.shade_mode = prm->shade_mode;
     k.setup_threshold = s->setup_threshold;
@@ -278,7 +278,7 @@ int ff_destroy(FfState* s)
     (void)hipSetDevice(s->device);
     if (s->pbo_resource) (void)hipGraphicsUnregisterResource(s->pbo_resource);
     free_scene(s);
-    if (s->d_accum) (void)hipFree(s->d_accum);
+    if (s->d_blocksums) (void)hipFree(s->d_blocksums);
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_rgb8) (void)hipFree(s->d_rgb8);
     if (s->d_radiance) (void)hipFree(s->d_radiance);

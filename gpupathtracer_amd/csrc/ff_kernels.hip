@@ -58,6 +58,7 @@ struct Counters {
     // phases are the counters above (nodes = inner-step lanes, tris = triangle-test lanes, planes, rays).
     unsigned inner_rounds, leaf_rounds, tri_rounds, plane_rounds, segment_rounds;
     unsigned no_mesh; // queries that needed no mesh traversal (planes only)
+    unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
 };
 
 // Count one wave-level round of a phase: exactly one of the active lanes (the lowest) records it.
@@ -477,6 +478,7 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
         float dist = ta * wlen; // approximate world distance
         if (!hit && ex <= 0.5f + delta && ey <= 0.5f + delta && q >= qlim * 0.99f && (front_sure || fabsf(num) <= 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz)))) {
             // within a margin: decide with the exact reference test (kernel.cu:138 + :8-32)
+            if (STATS) cnt.plane_exact += 1;
             Ray osr;
             float len;
             object_space_ray_lds(L, g, wr, osr, len);
@@ -1006,7 +1008,8 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
                                  pl = wave_sum((unsigned long long)cnt.planes);
         const unsigned long long r0 = wave_sum((unsigned long long)cnt.inner_rounds), r1 = wave_sum((unsigned long long)cnt.leaf_rounds),
                                  r2 = wave_sum((unsigned long long)cnt.tri_rounds), r3 = wave_sum((unsigned long long)cnt.plane_rounds),
-                                 r4 = wave_sum((unsigned long long)cnt.segment_rounds), r5 = wave_sum((unsigned long long)cnt.no_mesh);
+                                 r4 = wave_sum((unsigned long long)cnt.segment_rounds), r5 = wave_sum((unsigned long long)cnt.no_mesh),
+                                 r6 = wave_sum((unsigned long long)cnt.plane_exact);
         if (lane == 0) {
             if (n) atomicAdd(&p.counters[1], n);
             if (t) atomicAdd(&p.counters[2], t);
@@ -1017,6 +1020,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
             atomicAdd(&p.counters[11], r3);
             atomicAdd(&p.counters[12], r4);
             atomicAdd(&p.counters[14], r5);
+            atomicAdd(&p.counters[15], r6);
         }
     }
 }
@@ -1045,7 +1049,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     Segment S;
@@ -1169,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     }
     int n_ready = 0, n_finished = P; // wave-uniform
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int my_slot = -1; // slot whose query this lane is traversing
     Ray ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     Segment S;
@@ -1306,7 +1310,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     bool active = false, exhausted = false;
@@ -1348,7 +1352,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     }
     Best best;
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
     if (!live) return;

@@ -103,7 +103,7 @@ class FfStats(C.Structure):
     _fields_ = [
         ("rays_traced", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("planes_tested", C.c_uint64),
         ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-        ("kernel_launches", C.c_uint32), ("vgprs", C.c_uint32),
+        ("kernel_launches", C.c_uint32), ("_reserved", C.c_uint32),
         ("scene_bytes_nodes", C.c_uint64), ("scene_bytes_tris", C.c_uint64),
     ]
 

@@ -151,7 +151,8 @@ typedef struct FfRenderParams {
     int32_t  trace_mode;  /* FfTraceMode */
     int32_t  shade_mode;  /* FfShadeMode */
     int32_t  grid_mode;   /* FfGridMode */
-    int32_t  spp_per_launch; /* 0 = all spp in one launch; otherwise samples are rendered in chunks of this size */
+    int32_t  spp_per_launch; /* 0 = all samples in one kernel launch; otherwise a frame is rendered in several launches of about
+                                this many samples (rounded up to whole 64-sample blocks); the result does not depend on it */
 } FfRenderParams;
 
 /* Filled by ff_stats() after a render call. Counts are for the LAST ff_render* call on this state. */
@@ -163,7 +164,7 @@ typedef struct FfStats {
     double   kernel_ms;          /* sum of trace-kernel durations, HIP events on the launch stream */
     double   total_ms;           /* host wall clock of the whole call */
     uint32_t kernel_launches;    /* number of trace-kernel launches in the call */
-    uint32_t vgprs;              /* reserved */
+    uint32_t _reserved;          /* reserved */
     uint64_t scene_bytes_nodes;  /* device bytes of BVH nodes */
     uint64_t scene_bytes_tris;   /* device bytes of triangle records */
 } FfStats;
