@@ -59,6 +59,7 @@ struct Counters {
     unsigned inner_rounds, leaf_rounds, tri_rounds, plane_rounds, segment_rounds;
     unsigned no_mesh; // queries that needed no mesh traversal (planes only)
     unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
+    unsigned long long t_start, t_inner, t_leaf; // instrumented launches: wave cycles in mesh starts / inner phases / leaf phases
 };
 
 // Count one wave-level round of a phase: exactly one of the active lanes (the lowest) records it.
@@ -649,7 +650,10 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
     const int limit = budget > 0 ? budget : kLoopGuard;
     int rounds = 0, guard = 0;
     for (;;) {
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+        if (STATS) ta = __builtin_amdgcn_s_memtime();
         while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
+        if (STATS) tb = __builtin_amdgcn_s_memtime();
         if (__ballot(S.cur != kDone) == 0ull) break;
         for (;;) {
             const bool inner = S.cur >= 0 && S.cur != kDone;
@@ -660,7 +664,12 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
             ++rounds;
             if (inner) inner_step<STATS>(L, nodes, S, cnt);
         }
+        if (STATS) tc = __builtin_amdgcn_s_memtime();
         if (S.cur < 0) leaf_step<STATS>(L, tris, wr, S, cnt);
+        if (STATS) {
+            td = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_start += tb - ta; cnt.t_inner += tc - tb; cnt.t_leaf += td - tc; }
+        }
         if (__ballot(S.resume > 0) != 0ull) {
             if (S.resume > 0) {
                 HitPoint H;
@@ -1022,6 +1031,10 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
             atomicAdd(&p.counters[14], r5);
             atomicAdd(&p.counters[15], r6);
         }
+        {
+            const unsigned long long u0 = wave_sum(cnt.t_start), u1 = wave_sum(cnt.t_inner), u2 = wave_sum(cnt.t_leaf);
+            if (lane == 0) { atomicAdd(&p.counters[1 + 15], u0); atomicAdd(&p.counters[2 + 15], u1); atomicAdd(&p.counters[3 + 15], u2); }
+        }
     }
 }
 
@@ -1049,7 +1062,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     Segment S;
@@ -1173,7 +1186,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     }
     int n_ready = 0, n_finished = P; // wave-uniform
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int my_slot = -1; // slot whose query this lane is traversing
     Ray ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     Segment S;
@@ -1310,7 +1323,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     bool active = false, exhausted = false;
@@ -1352,7 +1365,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     }
     Best best;
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
     if (!live) return;

@@ -195,7 +195,7 @@ class Tracer:
         return st
 
     def debug_counters(self):
-        buf = (C.c_ulonglong * 16)()
+        buf = (C.c_ulonglong * 24)()
         check(self._lib.ff_debug_counters(self._state, buf))
         return list(buf)
 

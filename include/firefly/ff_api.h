@@ -147,11 +147,12 @@ FF_API int ff_render_to_pbo(FfState* state, const FfCamera* camera, const FfRend
 FF_API int ff_set_collect_stats(FfState* state, int on);
 FF_API int ff_stats(FfState* state, FfStats* out);
 
-/* Raw device counters of the last instrumented render (ff_set_collect_stats(1)), 16 values: [0] rays [1] inner-node
+/* Raw device counters of the last instrumented render (ff_set_collect_stats(1)), 24 values: [0] rays [1] inner-node
  * visits [2] triangle tests [3] plane tests (all summed over lanes) [8] inner-step rounds [9] leaf rounds [10] triangle
  * rounds [11] plane rounds [12] segment rounds (wave-level executions of each phase): lanes / (64 * rounds) is the SIMD
- * occupancy of that phase; [4..7],[13] wave cycles spent in resolve / shade / acquire / begin / traverse. */
-FF_API int ff_debug_counters(FfState* state, unsigned long long* out16);
+ * occupancy of that phase; [4..7],[13] wave cycles spent in resolve / shade / acquire / begin / traverse; [14] plane-only queries [15] exact plane
+ * tests; [16..18] wave cycles in mesh starts / inner-node phases / leaf phases. */
+FF_API int ff_debug_counters(FfState* state, unsigned long long* out24);
 
 /* ---- mesh loading (next-row scope: LoadMesh, utilities.h:781-840) ------------------------------- */
 

@@ -27,3 +27,7 @@ if tot:
     names = ["resolve", "shade", "acquire", "begin", "traverse"]
     vals = [c[4], c[5], c[6], c[7], c[13]]
     print("wave-cycle shares: " + "  ".join(f"{n} {v / tot:.3f}" for n, v in zip(names, vals)))
+tt = c[16] + c[17] + c[18]
+if tt:
+    print(f"traverse split: mesh-start {c[16] / tt:.3f}  inner {c[17] / tt:.3f}  leaf {c[18] / tt:.3f}   "
+          f"cycles per inner round {c[17] / max(ir, 1):.0f}  per triangle round {c[18] / max(tr, 1):.0f}")
