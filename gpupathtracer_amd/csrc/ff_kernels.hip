@@ -450,10 +450,20 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     S.resume = 0;
     const float wlen = __builtin_amdgcn_rcpf(inv_length(wr)); // |world direction| (1 for the integrator's rays)
 
+    // Stage 1, wave-uniform: which quads can the ray reach at all?  The padded world box of a quad is flat, so for the
+    // axis-aligned walls of a box scene this conservative slab test already singles out the one wall the ray hits.
+    const WorldSlab ws = make_world_slab(wr);
+    unsigned quads = 0u;
     for (int g = 0; g < num_planes; ++g) {
-        if (STATS) cnt.planes += 1;
-        // the record comes from the LDS copy at a wave-uniform address (broadcast reads; scalar loads from the global copy
-        // would serialise one ~L2-latency round trip per plane)
+        const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
+        if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << g;
+    }
+    // Stage 2, per lane: screen the lane's own candidates (records from the LDS copy at per-lane addresses).
+    for (int guard = 0; __ballot(quads != 0u) != 0ull && guard < 32; ++guard) {
+        if (quads == 0u) continue;
+        const int g = __ffs((int)quads) - 1;
+        quads &= quads - 1u;
+        if (STATS) { cnt.planes += 1; probe_round(cnt.plane_rounds); }
         const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
         const float4 pn = lds_geom4(L, g, 11);
         // object-space origin and un-normalised direction (screening only: FMA form)
@@ -497,7 +507,6 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
 
     // meshes: conservative world-box test against what the planes already found
     S.meshes = 0u;
-    const WorldSlab ws = make_world_slab(wr);
     const float limit = fminf(S.best.dist, S.pend.dist);
     for (int g = num_planes; g < num_geoms; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
