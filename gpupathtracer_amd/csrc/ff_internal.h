@@ -23,9 +23,9 @@ void clear_error();
 struct TriRecord {
     float v0[3];
     int32_t orig_index; // index j in Geometry::m_triangles
-    float v1[3];
-    int32_t pad0;
-    float v2[3];
+    float e1[3];        // v1 - v0, the fp32 subtraction of kernel.cu:44 done once on the host (same bits)
+    float cull_margin;  // if det >= EPSILON + cull_margin the back-face test of kernel.cu:49 cannot fire (see ff_scene.cpp)
+    float e2[3];        // v2 - v0 (kernel.cu:45)
     int32_t pad1;
 };
 static_assert(sizeof(TriRecord) == 48, "48-byte triangle record");

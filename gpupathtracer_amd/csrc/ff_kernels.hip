@@ -131,9 +131,9 @@ __device__ __forceinline__ void fill_object_normal(const GeomRecord* __restrict_
     if (best.geom < 0) return;
     if (best.rec >= 0) {
         const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)best.rec * 3;
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        const float4 b = tp[1], c = tp[2];
+        const float e1x = b.x, e1y = b.y, e1z = b.z;
+        const float e2x = c.x, e2y = c.y, e2z = c.z;
         best.cx = e1y * e2z - e2y * e1z;
         best.cy = e1z * e2x - e2z * e1x;
         best.cz = e1x * e2y - e2x * e1y;
@@ -146,10 +146,11 @@ __device__ __forceinline__ void fill_object_normal(const GeomRecord* __restrict_
 }
 
 // kernel.cu:35-108 (Möller-Trumbore, division deferred, back faces culled).  Returns the object-space t or -1.
-__device__ __forceinline__ float triangle_t(const float4 A, const float4 B, const float4 C, const Ray& r)
+// A = (v0, original index), E1 = (v1 - v0, cull margin), E2 = (v2 - v0, -): the edges of :44-45 come with the record.
+__device__ __forceinline__ float triangle_t(const float4 A, const float4 E1, const float4 E2, const Ray& r)
 {
-    const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z; // :44
-    const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z; // :45
+    const float e1x = E1.x, e1y = E1.y, e1z = E1.z; // :44
+    const float e2x = E2.x, e2y = E2.y, e2z = E2.z; // :45
     const float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y; // :48 glm cross
     if (dot3(r.dx, r.dy, r.dz, nx, ny, nz) > 0.0f) return -1.0f;                                        // :49
     const float px = r.dy * e2z - e2y * r.dz, py = r.dz * e2x - e2z * r.dx, pz = r.dx * e2y - e2x * r.dy; // :53
@@ -334,6 +335,7 @@ struct Segment {
     Ray osr;                   // object-space ray of the current mesh
     float ix, iy, iz, ox, oy, oz; // 1/d and -o/d of osr (box tests)
     float scale;               // object-space t per unit of world distance
+    float tbound;              // object-space ray parameter beyond which nothing can beat what the lane holds (box pruning)
     int resume;                // > 0: triangle resume-1 of the leaf under the cursor met a near tie with the pending candidate;
                                //      the caller resolves the pending one exactly, then the leaf continues from that triangle
 };
@@ -364,8 +366,8 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
         const float4 a = tp[0], b = tp[1], c = tp[2];
         orig_tri = __float_as_int(a.w);
         t = triangle_t(a, b, c, osr);
-        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        const float e1x = b.x, e1y = b.y, e1z = b.z;
+        const float e2x = c.x, e2y = c.y, e2z = c.z;
         H.cx = e1y * e2z - e2y * e1z; // kernel.cu:101 cross(edge1, edge2), shading normalises it where the reference does
         H.cy = e1z * e2x - e2z * e1x;
         H.cz = e1x * e2y - e2x * e1y;
@@ -515,6 +517,24 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
 }
 
+// Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
+// inner-node step reads one register instead of recomputing it per node.
+__device__ __forceinline__ void refresh_tbound(Segment& S)
+{
+    S.tbound = (fminf(S.best.dist, S.pend.dist) * 1.001f + 1.0e-3f) * S.scale * 1.00001f;
+}
+
+// Take the next subtree off the lane's stack.
+__device__ __forceinline__ void pop_subtree(const Lds& L, Segment& S)
+{
+    if (S.sp > 0) {
+        --S.sp;
+        S.cur = stack_pop(L, S.sp);
+    } else {
+        S.cur = kDone;
+    }
+}
+
 // Idle lane with candidate meshes left: enter the next one.
 __device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Segment& S)
 {
@@ -531,6 +551,7 @@ __device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Seg
     S.oy = -S.osr.oy * S.iy;
     S.oz = -S.osr.oz * S.iz;
     S.scale = len * inv_length(wr); // object-space t per unit of world distance
+    refresh_tbound(S);
     S.mesh = g;
     S.cur = root;
     S.sp = 0;
@@ -543,7 +564,7 @@ __device__ __forceinline__ void inner_step(const Lds& L, const BvhNode* __restri
     uint4 q0, q1, q2, q3;
     fetch_node(L, nodes, S.cur, q0, q1, q2, q3);
     if (STATS) { cnt.nodes += 1; probe_round(cnt.inner_rounds); }
-    const float tbound = (fminf(S.best.dist, S.pend.dist) * 1.001f + 1.0e-3f) * S.scale * 1.00001f;
+    const float tbound = S.tbound;
     // left box: q0.xyz = min, q1.xyz = max; right box: q2.xyz = min, q3.xyz = max (pruning only: FMA + approximate 1/d)
     float a0 = __builtin_fmaf(__uint_as_float(q0.x), S.ix, S.ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), S.ix, S.ox);
     float b0 = __builtin_fmaf(__uint_as_float(q0.y), S.iy, S.oy), b1 = __builtin_fmaf(__uint_as_float(q1.y), S.iy, S.oy);
@@ -566,11 +587,8 @@ __device__ __forceinline__ void inner_step(const Lds& L, const BvhNode* __restri
         S.cur = left;
     } else if (hr) {
         S.cur = right;
-    } else if (S.sp > 0) {
-        --S.sp;
-        S.cur = stack_pop(L, S.sp);
     } else {
-        S.cur = kDone;
+        pop_subtree(L, S);
     }
 }
 
@@ -588,12 +606,11 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
     S.resume = 0;
     if (STATS) probe_round(cnt.leaf_rounds);
     for (; k < count; ++k) {
-        const float4 A = tp[3 * k], B = tp[3 * k + 1], C = tp[3 * k + 2];
+        const float4 A = tp[3 * k], E1 = tp[3 * k + 1], E2 = tp[3 * k + 2];
         if (STATS) { cnt.tris += 1; probe_round(cnt.tri_rounds); }
         // kernel.cu:44-75: exact up to the division; every accept/reject comparison is the reference's own
-        const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
-        const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
-        const float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
+        const float e1x = E1.x, e1y = E1.y, e1z = E1.z;
+        const float e2x = E2.x, e2y = E2.y, e2z = E2.z;
         const float px = r.dy * e2z - e2y * r.dz, py = r.dz * e2x - e2z * r.dx, pz = r.dx * e2y - e2x * r.dy;
         const float det = dot3(e1x, e1y, e1z, px, py, pz);
         const float tx = r.ox - A.x, ty = r.oy - A.y, tz = r.oz - A.z;
@@ -601,7 +618,12 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
         const float qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
         const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz);
         const float tn = dot3(e2x, e2y, e2z, qx, qy, qz);
-        bool ok = !(dot3(r.dx, r.dy, r.dz, nx, ny, nz) > 0.0f) && !(det < kTriEpsilon) && !(u < 0.0f || u > det) && !(v < 0.0f || u + v > det);
+        bool ok = !(det < kTriEpsilon) && !(u < 0.0f || u > det) && !(v < 0.0f || u + v > det);
+        if (ok && det < kTriEpsilon + E1.w) {
+            // the back-face test of kernel.cu:48-49 could disagree with the sign of det only this close to edge-on
+            const float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
+            ok = !(dot3(r.dx, r.dy, r.dz, nx, ny, nz) > 0.0f);
+        }
         if (ok) {
             float ta = tn * __builtin_amdgcn_rcpf(det); // approximate t (kernel.cu:77-79 is exact: 1/det, then multiply)
             if (ta < kTriEpsilon * 1.001f) {
@@ -618,13 +640,9 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
             }
         }
     }
+    refresh_tbound(S);
     if (S.resume > 0) return;
-    if (S.sp > 0) {
-        --S.sp;
-        S.cur = stack_pop(L, S.sp);
-    } else {
-        S.cur = kDone;
-    }
+    pop_subtree(L, S);
 }
 
 // Settle what is still pending (the common case: the one exact evaluation of the ray, all hitting lanes together) and
@@ -683,6 +701,7 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
             if (S.resume > 0) {
                 HitPoint H;
                 resolve_pending(L, tris, wr, S.pend, S.best, H);
+                refresh_tbound(S);
             }
         }
         if (rounds >= limit) break;
@@ -1082,6 +1101,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
     S.scale = 1.f;
+    S.tbound = 0.f;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
@@ -1206,6 +1226,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     S.osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
     S.scale = 1.f;
+    S.tbound = 0.f;
 
     for (int guard = 0; guard < (1 << 28); ++guard) {
         const int running = __popcll(__ballot(my_slot >= 0));

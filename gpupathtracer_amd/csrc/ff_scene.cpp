@@ -231,8 +231,18 @@ int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams&
         TriRecord r;
         std::memset(&r, 0, sizeof r);
         std::memcpy(r.v0, &t.m_v0, 12);
-        std::memcpy(r.v1, &t.m_v1, 12);
-        std::memcpy(r.v2, &t.m_v2, 12);
+        // Edges exactly as the reference forms them per test (kernel.cu:44-45: one fp32 subtraction per component).
+        const float e1[3] = { t.m_v1.x - t.m_v0.x, t.m_v1.y - t.m_v0.y, t.m_v1.z - t.m_v0.z };
+        const float e2[3] = { t.m_v2.x - t.m_v0.x, t.m_v2.y - t.m_v0.y, t.m_v2.z - t.m_v0.z };
+        std::memcpy(r.e1, e1, 12);
+        std::memcpy(r.e2, e2, 12);
+        // kernel.cu:49 rejects when dot(d, cross(e1, e2)) > 0 and kernel.cu:57 when det = dot(e1, cross(d, e2)) < EPSILON.
+        // In exact arithmetic det = -dot(d, cross(e1, e2)); each computed value is off by at most 6 roundings of terms
+        // whose magnitudes sum to |d|_max * |e1|_1 * |e2|_1 (|d|_max <= 1 + 3 ulp: the direction is normalised).  So when
+        // det >= EPSILON + 2 * 8 eps * |e1|_1 |e2|_1 the back-face test is certain to pass and the kernel skips it; the
+        // margin stored here is twice that again, rounded up.
+        const double m = ((double)std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2])) * ((double)std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
+        r.cull_margin = std::nextafter((float)(32.0 * 5.9604644775390625e-8 * m), 3.0e38f);
         r.orig_index = B.perm[i];
         tris.push_back(r);
     }
@@ -430,7 +440,10 @@ bool check_bvh(const CompiledScene& cs, int* out_max_leaf)
                 for (int i = first; i < first + count; ++i) {
                     ++seen[i];
                     const TriRecord& t = cs.tris[i];
-                    for (const float* v : { t.v0, t.v1, t.v2 })
+                    // (v0 + e within an ulp of the vertex; the boxes carry a padding of 1e-4 of the mesh extent)
+                    const float v1[3] = { t.v0[0] + t.e1[0], t.v0[1] + t.e1[1], t.v0[2] + t.e1[2] };
+                    const float v2[3] = { t.v0[0] + t.e2[0], t.v0[1] + t.e2[1], t.v0[2] + t.e2[2] };
+                    for (const float* v : { t.v0, v1, v2 })
                         for (int k = 0; k < 3; ++k)
                             if (!(v[k] >= it.mn[k] && v[k] <= it.mx[k])) ok = false;
                 }
