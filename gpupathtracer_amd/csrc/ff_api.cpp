@@ -44,7 +44,7 @@ struct FfState {
     int pool_slots = 192, pool_refill = 16, pool_low = 24;
     unsigned* d_pool = nullptr;
     size_t pool_bytes = 0;
-    int setup_threshold = 14, leaf_threshold = 24; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
+    int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
     unsigned long long raw_counters[24] = {};

@@ -60,6 +60,7 @@ struct Counters {
     unsigned no_mesh; // queries that needed no mesh traversal (planes only)
     unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
     unsigned long long t_start, t_inner, t_leaf; // instrumented launches: wave cycles in mesh starts / inner phases / leaf phases
+    unsigned long long t_b1, t_b2, t_b3;         // ... and in the three parts of begin_segment (quad boxes / quad screens / mesh boxes)
 };
 
 // Count one wave-level round of a phase: exactly one of the active lanes (the lowest) records it.
@@ -181,7 +182,7 @@ __device__ __forceinline__ float plane_t(float nx, float ny, float nz, const Ray
 
 // ---- LDS layout of the BVH kernels -----------------------------------------------------------------------------------
 //
-//   [ nodes: lds_nodes x 64 B ][ traversal stacks: stack_depth x BLOCK x 4 B, lane-strided ][ geometry records: G x 288 B ]
+//   [ nodes: 4 planes of lds_nodes x 16 B ][ traversal stacks: stack_depth x BLOCK x 4 B, lane-strided ][ geometry records: G x 288 B ]
 //
 // ff_smem is indexed directly (never through a generic pointer) so that every access compiles to ds_read/ds_write.
 extern __shared__ uint4 ff_smem[];
@@ -211,8 +212,11 @@ __device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int bloc
 __device__ __forceinline__ void stage_scene(const Lds& L, const BvhNode* __restrict__ nodes, const GeomRecord* __restrict__ geoms, int num_geoms,
                                             int tid, int block)
 {
+    // Nodes are stored as four planes of 16-byte quarters (quarter k of node i at uint4 index k * node_count + i): lanes
+    // fetch quarter k of unrelated nodes with one ds_read_b128, and in this layout those addresses spread over all LDS
+    // banks, whereas whole 64-byte nodes would put every lane's quarter k on the same quarter of the banks.
     const uint4* src = reinterpret_cast<const uint4*>(nodes);
-    for (int i = tid; i < L.node_count * 4; i += block) ff_smem[i] = src[i];
+    for (int i = tid; i < L.node_count * 4; i += block) ff_smem[(i & 3) * L.node_count + (i >> 2)] = src[i];
     const uint4* gsrc = reinterpret_cast<const uint4*>(geoms);
     for (int i = tid; i < num_geoms * kGeomVec4; i += block) ff_smem[L.geom_base + i] = gsrc[i];
     __syncthreads();
@@ -232,10 +236,10 @@ __device__ __forceinline__ int stack_pop(const Lds& L, int sp) { return reinterp
 __device__ __forceinline__ void fetch_node(const Lds& L, const BvhNode* __restrict__ nodes, int cur, uint4& q0, uint4& q1, uint4& q2, uint4& q3)
 {
     if (cur < L.node_count) {
-        q0 = ff_smem[cur * 4];
-        q1 = ff_smem[cur * 4 + 1];
-        q2 = ff_smem[cur * 4 + 2];
-        q3 = ff_smem[cur * 4 + 3];
+        q0 = ff_smem[cur];
+        q1 = ff_smem[cur + L.node_count];
+        q2 = ff_smem[cur + 2 * L.node_count];
+        q3 = ff_smem[cur + 3 * L.node_count];
     } else {
         const uint4* p = reinterpret_cast<const uint4*>(nodes) + (size_t)cur * 4;
         q0 = p[0];
@@ -454,12 +458,15 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
 
     // Stage 1, wave-uniform: which quads can the ray reach at all?  The padded world box of a quad is flat, so for the
     // axis-aligned walls of a box scene this conservative slab test already singles out the one wall the ray hits.
+    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
+    if (STATS) tb0 = __builtin_amdgcn_s_memtime();
     const WorldSlab ws = make_world_slab(wr);
     unsigned quads = 0u;
     for (int g = 0; g < num_planes; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
         if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << g;
     }
+    if (STATS) tb1 = __builtin_amdgcn_s_memtime();
     // Stage 2, per lane: screen the lane's own candidates (records from the LDS copy at per-lane addresses).
     for (int guard = 0; __ballot(quads != 0u) != 0ull && guard < 32; ++guard) {
         if (quads == 0u) continue;
@@ -507,6 +514,7 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
         }
     }
 
+    if (STATS) tb2 = __builtin_amdgcn_s_memtime();
     // meshes: conservative world-box test against what the planes already found
     S.meshes = 0u;
     const float limit = fminf(S.best.dist, S.pend.dist);
@@ -515,6 +523,10 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
         if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << g;
     }
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
+    if (STATS) {
+        const unsigned long long tb3 = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_b1 += tb1 - tb0; cnt.t_b2 += tb2 - tb1; cnt.t_b3 += tb3 - tb2; }
+    }
 }
 
 // Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
@@ -1062,6 +1074,8 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
         {
             const unsigned long long u0 = wave_sum(cnt.t_start), u1 = wave_sum(cnt.t_inner), u2 = wave_sum(cnt.t_leaf);
             if (lane == 0) { atomicAdd(&p.counters[1 + 15], u0); atomicAdd(&p.counters[2 + 15], u1); atomicAdd(&p.counters[3 + 15], u2); }
+            const unsigned long long w0 = wave_sum(cnt.t_b1), w1 = wave_sum(cnt.t_b2), w2 = wave_sum(cnt.t_b3);
+            if (lane == 0) { atomicAdd(&p.counters[19], w0); atomicAdd(&p.counters[20], w1); atomicAdd(&p.counters[21], w2); }
         }
     }
 }
@@ -1090,7 +1104,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     Segment S;
@@ -1215,7 +1229,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     }
     int n_ready = 0, n_finished = P; // wave-uniform
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int my_slot = -1; // slot whose query this lane is traversing
     Ray ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     Segment S;
@@ -1353,7 +1367,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
     init_path(P);
     bool active = false, exhausted = false;
@@ -1395,7 +1409,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     }
     Best best;
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
     if (!live) return;
