@@ -12,6 +12,7 @@
 // (the interop header relies on hip_runtime.h having been included first)
 #include <hip/hip_gl_interop.h>
 
+#include "ff_build.h"
 #include "ff_internal.h"
 #include "ff_kernels.h"
 
@@ -28,6 +29,21 @@ struct FfState {
     int num_geoms = 0, num_planes = 0, num_nodes = 0, max_depth = 0;
     uint64_t num_tris = 0;
     bool has_scene = false;
+    // scene bookkeeping for updates (ff_update_transforms / ff_update_mesh)
+    struct MeshSlot {
+        int node_first = 0, node_count = 0, node_capacity = 0, depth = 0;
+        bool parents_linked = false;
+    };
+    int builder = FF_BUILD_HOST_SAH;       // builder for the next upload (ff_set_builder)
+    int scene_builder = FF_BUILD_HOST_SAH; // builder that produced the scene on the device
+    std::vector<GeomRecord> h_geoms;       // the uploaded records, processing order
+    std::vector<MeshSlot> slots;           // parallel to h_geoms (meshes only)
+    size_t node_capacity = 0;              // nodes allocated in d_nodes
+    int* d_parent = nullptr;               // node_capacity ints (refit)
+    FfTriangle* d_stage = nullptr;         // staging copy of a caller triangle array (device builder / refit)
+    size_t stage_bytes = 0;
+    BuildScratch scratch;
+    FfBuildStats build_stats = {};
     // work buffers (device)
     float* d_blocksums = nullptr;
     size_t blocksums_bytes = 0;
@@ -66,9 +82,14 @@ void free_scene(FfState* s)
     if (s->d_geoms) (void)hipFree(s->d_geoms);
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_parent) (void)hipFree(s->d_parent);
     s->d_geoms = nullptr;
     s->d_tris = nullptr;
     s->d_nodes = nullptr;
+    s->d_parent = nullptr;
+    s->h_geoms.clear();
+    s->slots.clear();
+    s->node_capacity = 0;
     s->has_scene = false;
     s->num_geoms = s->num_nodes = s->max_depth = 0;
     s->num_tris = 0;
@@ -278,6 +299,8 @@ int ff_destroy(FfState* s)
     (void)hipSetDevice(s->device);
     if (s->pbo_resource) (void)hipGraphicsUnregisterResource(s->pbo_resource);
     free_scene(s);
+    if (s->d_stage) (void)hipFree(s->d_stage);
+    free_build_scratch(s->scratch);
     if (s->d_blocksums) (void)hipFree(s->d_blocksums);
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_rgb8) (void)hipFree(s->d_rgb8);
@@ -298,16 +321,152 @@ int ff_set_stream(FfState* s, void* hip_stream)
     return FF_OK;
 }
 
+namespace {
+
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Copy a caller triangle array into the device staging buffer (input of the device builder and of refit).
+int stage_triangles(FfState* s, const FfTriangle* tris, int count, double* copy_ms)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    int st = ensure_bytes((void**)&s->d_stage, &s->stage_bytes, (size_t)count * sizeof(FfTriangle));
+    if (st != FF_OK) return st;
+    FF_HIP(hipMemcpyAsync(s->d_stage, tris, (size_t)count * sizeof(FfTriangle), hipMemcpyHostToDevice, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    *copy_ms += ms_since(t0);
+    return FF_OK;
+}
+
+// A mesh that fits one leaf: the host builder's single node, re-based into the device arrays.
+int place_single_leaf_mesh(FfState* s, const FfTriangle* tris, int count, const BvhBuildParams& bp, int tri_first, int node_base, int* out_nodes, int* out_depth)
+{
+    std::vector<BvhNode> tn;
+    std::vector<TriRecord> tt;
+    int depth = 0;
+    build_mesh_bvh(tris, count, bp, tn, tt, &depth);
+    for (BvhNode& nd : tn) {
+        int* links[2] = { &nd.left, &nd.right };
+        for (int* l : links) {
+            if (*l >= 0) {
+                *l += node_base;
+            } else {
+                const int ref = ~*l;
+                *l = ~((((ref >> 3) + tri_first) << 3) | (ref & 7));
+            }
+        }
+    }
+    FF_HIP(hipMemcpy(s->d_nodes + node_base, tn.data(), tn.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    FF_HIP(hipMemcpy(s->d_tris + tri_first, tt.data(), tt.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
+    *out_nodes = (int)tn.size();
+    *out_depth = depth;
+    return FF_OK;
+}
+
+void refresh_scene_extent(FfState* s)
+{
+    int end = 0, depth = 0;
+    for (size_t i = 0; i < s->slots.size(); ++i) {
+        if (s->h_geoms[i].type != FF_GEOM_TRIANGLEMESH || s->slots[i].node_count == 0) continue;
+        end = std::max(end, s->slots[i].node_first + s->slots[i].node_count);
+        depth = std::max(depth, s->slots[i].depth);
+    }
+    s->num_nodes = end;
+    s->max_depth = depth;
+    s->build_stats.builder = s->scene_builder;
+    s->build_stats.bvh_nodes = end;
+    s->build_stats.bvh_max_depth = depth;
+    s->build_stats.num_triangles = s->num_tris;
+}
+
+int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, int n, const BvhBuildParams& bp)
+{
+    FfBuildStats& bs = s->build_stats;
+    CompiledScene cs;
+    int st = compile_scene(host_geometries, n, bp, cs, /*build_bvh=*/false);
+    if (st != FF_OK) return st;
+    FF_HIP(hipSetDevice(s->device));
+    free_scene(s);
+    size_t node_cap = 0;
+    for (const GeomRecord& g : cs.geoms)
+        if (g.type == FF_GEOM_TRIANGLEMESH && g.tri_count > 0) node_cap += gpu_build_max_nodes(g.tri_count);
+    FF_HIP(hipMalloc((void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
+    FF_HIP(hipMalloc((void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
+    FF_HIP(hipMalloc((void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
+    s->node_capacity = node_cap;
+    s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
+    int node_base = 0;
+    for (size_t gi = 0; gi < cs.geoms.size(); ++gi) {
+        GeomRecord& r = cs.geoms[gi];
+        if (r.type != FF_GEOM_TRIANGLEMESH || r.tri_count <= 0) continue;
+        const FfTriangle* src = host_geometries[r.orig_index].m_triangles;
+        FfState::MeshSlot& slot = s->slots[gi];
+        slot.node_first = node_base;
+        slot.node_capacity = (int)gpu_build_max_nodes(r.tri_count);
+        if (r.tri_count <= bp.max_leaf_tris) {
+            st = place_single_leaf_mesh(s, src, r.tri_count, bp, r.tri_first, node_base, &slot.node_count, &slot.depth);
+            if (st != FF_OK) return st;
+        } else {
+            st = stage_triangles(s, src, r.tri_count, &bs.copy_ms);
+            if (st != FF_OK) return st;
+            const auto t0 = std::chrono::steady_clock::now();
+            MeshBuildInfo info;
+            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, r.tri_count, r.tri_first, node_base, bp.max_leaf_tris, s->d_tris, s->d_nodes, &info);
+            if (st != FF_OK) return st;
+            FF_HIP(hipStreamSynchronize(s->stream));
+            bs.build_ms += ms_since(t0);
+            slot.node_count = info.node_count;
+            slot.depth = info.depth;
+        }
+        r.bvh_root = node_base;
+        node_base += slot.node_capacity;
+    }
+    FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
+    s->h_geoms = cs.geoms;
+    s->num_geoms = (int)cs.geoms.size();
+    s->num_planes = 0;
+    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type == FF_GEOM_PLANE ? 1 : 0;
+    s->num_tris = cs.total_tris;
+    s->scene_builder = FF_BUILD_GPU_LBVH;
+    refresh_scene_extent(s);
+    s->has_scene = true;
+    return FF_OK;
+}
+
+} // namespace
+
+int ff_set_builder(FfState* s, int builder)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_set_builder: state is null");
+    if (builder != FF_BUILD_HOST_SAH && builder != FF_BUILD_GPU_LBVH) return fail(FF_ERR_INVALID_ARG, "ff_set_builder: unknown builder %d", builder);
+    s->builder = builder;
+    return FF_OK;
+}
+
 int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
 {
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_upload_scene: state is null");
-    CompiledScene cs;
+    const auto t_call = std::chrono::steady_clock::now();
+    s->build_stats = FfBuildStats();
     const BvhBuildParams bp = default_bvh_params();
+    if (s->builder == FF_BUILD_GPU_LBVH) {
+        const int st = upload_with_device_builder(s, host_geometries, n, bp);
+        s->build_stats.total_ms = ms_since(t_call);
+        if (st != FF_OK) free_scene(s);
+        return st;
+    }
+    CompiledScene cs;
+    const auto t_build = std::chrono::steady_clock::now();
     int st = compile_scene(host_geometries, n, bp, cs);
     if (st != FF_OK) return st;
+    s->build_stats.build_ms = ms_since(t_build);
     FF_HIP(hipSetDevice(s->device));
     free_scene(s);
+    const auto t_copy = std::chrono::steady_clock::now();
     // One allocation + one copy per array (the reference issues a cudaMallocManaged + two cudaMemcpy per geometry, kernel.cu:277-298).
     FF_HIP(hipMalloc((void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
     FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
@@ -318,13 +477,166 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     FF_HIP(hipMalloc((void**)&s->d_nodes, node_bytes));
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    s->build_stats.copy_ms = ms_since(t_copy);
     s->num_geoms = (int)cs.geoms.size();
     s->num_planes = 0;
     for (const GeomRecord& g : cs.geoms) s->num_planes += g.type == FF_GEOM_PLANE ? 1 : 0;
-    s->num_nodes = (int)cs.nodes.size();
     s->num_tris = cs.tris.size();
+    s->node_capacity = cs.nodes.size();
+    // Each mesh's nodes are contiguous with the root first: slot = [root, next mesh's root).
+    s->h_geoms = cs.geoms;
+    s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
+    std::vector<int> roots;
+    for (const GeomRecord& g : cs.geoms)
+        if (g.type == FF_GEOM_TRIANGLEMESH && g.bvh_root >= 0) roots.push_back(g.bvh_root);
+    std::sort(roots.begin(), roots.end());
+    for (size_t gi = 0; gi < cs.geoms.size(); ++gi) {
+        const GeomRecord& g = cs.geoms[gi];
+        if (g.type != FF_GEOM_TRIANGLEMESH || g.bvh_root < 0) continue;
+        const auto next = std::upper_bound(roots.begin(), roots.end(), g.bvh_root);
+        FfState::MeshSlot& slot = s->slots[gi];
+        slot.node_first = g.bvh_root;
+        slot.node_count = (next == roots.end() ? (int)cs.nodes.size() : *next) - g.bvh_root;
+        slot.node_capacity = slot.node_count;
+        slot.depth = cs.max_depth; // per-mesh depths are not kept by the host compiler; the scene maximum is a valid bound
+    }
+    s->scene_builder = FF_BUILD_HOST_SAH;
+    refresh_scene_extent(s);
+    s->num_nodes = (int)cs.nodes.size();
     s->max_depth = cs.max_depth;
+    s->build_stats.bvh_nodes = s->num_nodes;
+    s->build_stats.bvh_max_depth = s->max_depth;
     s->has_scene = true;
+    s->build_stats.total_ms = ms_since(t_call);
+    return FF_OK;
+}
+
+int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: state is null");
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_update_transforms: no scene uploaded");
+    const auto t_call = std::chrono::steady_clock::now();
+    CompiledScene cs;
+    int st = compile_scene(host_geometries, n, default_bvh_params(), cs, /*build_bvh=*/false);
+    if (st != FF_OK) return st;
+    if (cs.geoms.size() != s->h_geoms.size()) return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: %d geometries, the uploaded scene has %zu", n, s->h_geoms.size());
+    for (size_t i = 0; i < cs.geoms.size(); ++i) {
+        GeomRecord& a = cs.geoms[i];
+        const GeomRecord& b = s->h_geoms[i];
+        if (a.type != b.type || a.orig_index != b.orig_index || a.tri_count != b.tri_count || a.tri_first != b.tri_first)
+            return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: geometry %d differs in kind or triangle count from the uploaded one", a.orig_index);
+        a.bvh_root = b.bvh_root;
+    }
+    FF_HIP(hipSetDevice(s->device));
+    FF_HIP(hipMemcpyAsync(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    s->h_geoms = cs.geoms;
+    s->build_stats.last_operation = 3;
+    s->build_stats.total_ms = ms_since(t_call);
+    s->build_stats.copy_ms = s->build_stats.total_ms;
+    s->build_stats.build_ms = 0.0;
+    return FF_OK;
+}
+
+int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, int count, int mode)
+{
+    clear_error();
+    if (!s || !triangles) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: null argument");
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_update_mesh: no scene uploaded");
+    if (mode != FF_UPDATE_REFIT && mode != FF_UPDATE_REBUILD) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: unknown mode %d", mode);
+    int gi = -1;
+    for (size_t i = 0; i < s->h_geoms.size(); ++i)
+        if (s->h_geoms[i].orig_index == geometry_index) gi = (int)i;
+    if (gi < 0 || s->h_geoms[gi].type != FF_GEOM_TRIANGLEMESH) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: geometry %d is not an uploaded mesh", geometry_index);
+    GeomRecord& rec = s->h_geoms[gi];
+    if (count != rec.tri_count || count <= 0) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: %d triangles, the uploaded mesh has %d", count, rec.tri_count);
+    if (mode == FF_UPDATE_REBUILD && s->scene_builder != FF_BUILD_GPU_LBVH)
+        return fail(FF_ERR_UNSUPPORTED, "ff_update_mesh: rebuilding in place needs a scene uploaded with FF_BUILD_GPU_LBVH (host-built trees are packed)");
+    const auto t_call = std::chrono::steady_clock::now();
+    FfBuildStats& bs = s->build_stats;
+    bs.copy_ms = bs.build_ms = 0.0;
+    FF_HIP(hipSetDevice(s->device));
+    FfState::MeshSlot& slot = s->slots[gi];
+    const BvhBuildParams bp = default_bvh_params();
+    int st = stage_triangles(s, triangles, count, &bs.copy_ms);
+    if (st != FF_OK) return st;
+    const auto t_build = std::chrono::steady_clock::now();
+    if (mode == FF_UPDATE_REBUILD) {
+        if (count <= bp.max_leaf_tris) {
+            st = place_single_leaf_mesh(s, triangles, count, bp, rec.tri_first, slot.node_first, &slot.node_count, &slot.depth);
+        } else {
+            MeshBuildInfo info;
+            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, bp.max_leaf_tris, s->d_tris, s->d_nodes, &info);
+            slot.node_count = info.node_count;
+            slot.depth = info.depth;
+        }
+        if (st != FF_OK) return st;
+        slot.parents_linked = false;
+        bs.last_operation = 2;
+    } else {
+        if (!s->d_parent) FF_HIP(hipMalloc((void**)&s->d_parent, (s->node_capacity ? s->node_capacity : 1) * sizeof(int)));
+        if (!slot.parents_linked) {
+            st = gpu_link_parents(s->stream, s->d_nodes, slot.node_first, slot.node_count, s->d_parent + slot.node_first);
+            if (st != FF_OK) return st;
+            slot.parents_linked = true;
+        }
+        st = gpu_refit_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, slot.node_count, s->d_parent + slot.node_first, s->d_tris,
+                            s->d_nodes);
+        if (st != FF_OK) return st;
+        bs.last_operation = 1;
+    }
+    // the geometry's world box follows the new vertices
+    float omn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, omx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (int t = 0; t < count; ++t) {
+        const FfVec3* v[3] = { &triangles[t].m_v0, &triangles[t].m_v1, &triangles[t].m_v2 };
+        for (const FfVec3* p : v) {
+            omn[0] = std::min(omn[0], p->x); omn[1] = std::min(omn[1], p->y); omn[2] = std::min(omn[2], p->z);
+            omx[0] = std::max(omx[0], p->x); omx[1] = std::max(omx[1], p->y); omx[2] = std::max(omx[2], p->z);
+        }
+    }
+    set_world_box(rec, omn, omx);
+    FF_HIP(hipMemcpyAsync(s->d_geoms + gi, &rec, sizeof(GeomRecord), hipMemcpyHostToDevice, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    bs.build_ms = ms_since(t_build);
+    refresh_scene_extent(s);
+    if (s->scene_builder == FF_BUILD_HOST_SAH) s->num_nodes = (int)s->node_capacity;
+    bs.total_ms = ms_since(t_call);
+    return FF_OK;
+}
+
+int ff_build_stats(FfState* s, FfBuildStats* out)
+{
+    clear_error();
+    if (!s || !out) return fail(FF_ERR_INVALID_ARG, "ff_build_stats: null argument");
+    *out = s->build_stats;
+    return FF_OK;
+}
+
+int ff_debug_download_bvh(FfState* s, void* nodes, int max_nodes, int* out_nodes, void* tris, int max_tris, int* out_tris, int* mesh_table,
+                          int max_geometries)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_debug_download_bvh: state is null");
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_debug_download_bvh: no scene uploaded");
+    if (out_nodes) *out_nodes = s->num_nodes;
+    if (out_tris) *out_tris = (int)s->num_tris;
+    FF_HIP(hipSetDevice(s->device));
+    if (nodes && max_nodes > 0) FF_HIP(hipMemcpy(nodes, s->d_nodes, (size_t)std::min(max_nodes, s->num_nodes) * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    if (tris && max_tris > 0) FF_HIP(hipMemcpy(tris, s->d_tris, (size_t)std::min<uint64_t>((uint64_t)max_tris, s->num_tris) * sizeof(TriRecord), hipMemcpyDeviceToHost));
+    if (mesh_table) {
+        for (size_t i = 0; i < s->h_geoms.size(); ++i) {
+            const GeomRecord& g = s->h_geoms[i];
+            if (g.orig_index < 0 || g.orig_index >= max_geometries) continue;
+            int* row = mesh_table + 5 * g.orig_index;
+            const bool mesh = g.type == FF_GEOM_TRIANGLEMESH && g.bvh_root >= 0;
+            row[0] = mesh ? g.bvh_root : -1;
+            row[1] = mesh ? s->slots[i].node_count : 0;
+            row[2] = g.tri_first;
+            row[3] = g.tri_count;
+            row[4] = mesh ? s->slots[i].depth : 0;
+        }
+    }
     return FF_OK;
 }
 

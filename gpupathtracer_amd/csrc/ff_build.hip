@@ -1,0 +1,543 @@
+// ff_build.hip — LBVH construction and BVH refit on the device (gfx950).  See ff_build.h.
+//
+// Per mesh (T triangles, object space):
+//   bounds    vertex AABB, wave-reduced then 6 ordered-integer atomics per wave
+//   morton    63-bit Morton code of each triangle's centroid (21 bits per axis inside the AABB) + triangle id
+//   sort      rocprim::radix_sort_pairs on the codes
+//   hierarchy Karras 2012: one thread per internal node finds its range and split from common-prefix lengths
+//             (ties between equal codes are broken by position, so the tree is well-formed for duplicate centroids)
+//   fit       one thread per leaf walks up; the second thread to reach a node merges its children's boxes
+//   rank      every internal node whose range holds more than max_leaf triangles becomes a 64-byte traversal node;
+//             they are ranked by depth with a second radix sort, so node numbers grow level by level (root first)
+//   emit      traversal nodes (both child boxes padded like the host builder's, links to nodes / collapsed leaves)
+//   records   TriRecords in sorted (= leaf) order
+//
+// Refit: triangle records are rewritten from the new vertices, leaf boxes recomputed, and complete nodes propagate their
+// union into the parent's child slot; a per-node arrival counter (2 arrivals = both child boxes final) decides which
+// thread continues upward, so no thread ever waits for another.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ff_build.h"
+
+namespace ff {
+
+namespace {
+
+constexpr int kBuildBlock = 256;
+constexpr int kWaveSize = 64;
+constexpr unsigned kNotEmitted = 255u; // depth key of internal nodes that are collapsed into leaves
+
+#define FFB_HIP(call)                                                                                                    \
+    do {                                                                                                                 \
+        hipError_t _e = (call);                                                                                          \
+        if (_e != hipSuccess) return fail(FF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline int grid_for(long long n) { return (int)((n + kBuildBlock - 1) / kBuildBlock); }
+
+// float <-> int with the same ordering (for atomicMin / atomicMax on floats)
+__device__ __forceinline__ int ordered_int(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+struct Box6 {
+    float mn[3], mx[3];
+};
+
+__device__ __forceinline__ void grow(Box6& b, const FfVec3& v)
+{
+    b.mn[0] = fminf(b.mn[0], v.x); b.mn[1] = fminf(b.mn[1], v.y); b.mn[2] = fminf(b.mn[2], v.z);
+    b.mx[0] = fmaxf(b.mx[0], v.x); b.mx[1] = fmaxf(b.mx[1], v.y); b.mx[2] = fmaxf(b.mx[2], v.z);
+}
+__device__ __forceinline__ Box6 empty_box()
+{
+    const float inf = __builtin_huge_valf();
+    return Box6{ { inf, inf, inf }, { -inf, -inf, -inf } };
+}
+
+__global__ void init_bounds_kernel(int* bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = ordered_int(__builtin_huge_valf());
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = ordered_int(-__builtin_huge_valf());
+}
+
+__global__ __launch_bounds__(kBuildBlock) void bounds_kernel(const FfTriangle* __restrict__ src, int T, int* bounds)
+{
+    Box6 b = empty_box();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x) {
+        grow(b, src[i].m_v0);
+        grow(b, src[i].m_v1);
+        grow(b, src[i].m_v2);
+    }
+    for (int off = kWaveSize / 2; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; ++k) {
+            b.mn[k] = fminf(b.mn[k], __shfl_xor(b.mn[k], off));
+            b.mx[k] = fmaxf(b.mx[k], __shfl_xor(b.mx[k], off));
+        }
+    }
+    if ((threadIdx.x & (kWaveSize - 1)) == 0) {
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&bounds[k], ordered_int(b.mn[k]));
+            atomicMax(&bounds[3 + k], ordered_int(b.mx[k]));
+        }
+    }
+}
+
+// Spread the low 21 bits of v so that two zero bits follow each of them.
+__device__ __forceinline__ uint64_t spread21(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void morton_kernel(const FfTriangle* __restrict__ src, int T, const int* __restrict__ bounds,
+                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const FfTriangle& t = src[i];
+    const float c[3] = { (t.m_v0.x + t.m_v1.x + t.m_v2.x) * (1.0f / 3.0f), (t.m_v0.y + t.m_v1.y + t.m_v2.y) * (1.0f / 3.0f),
+                         (t.m_v0.z + t.m_v1.z + t.m_v2.z) * (1.0f / 3.0f) };
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = ordered_float(bounds[k]), hi = ordered_float(bounds[3 + k]);
+        const float ext = hi - lo;
+        const float n = ext > 0.0f ? (c[k] - lo) / ext : 0.5f;
+        q[k] = (uint32_t)fminf(fmaxf(n * 2097152.0f, 0.0f), 2097151.0f);
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    vals[i] = (uint32_t)i;
+}
+
+// Length of the common prefix of the (code, position) keys at sorted positions i and j; -1 outside the array.
+__device__ __forceinline__ int common_prefix(const uint64_t* __restrict__ keys, int T, int i, int j)
+{
+    if (j < 0 || j >= T) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz(i ^ j);
+    return __clzll((long long)(a ^ b));
+}
+
+// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", section 4.
+// Children: >= 0 internal node index, < 0 leaf at sorted position ~child.
+__global__ __launch_bounds__(kBuildBlock) void hierarchy_kernel(const uint64_t* __restrict__ keys, int T, int* __restrict__ left, int* __restrict__ right,
+                                                                 int* __restrict__ first, int* __restrict__ last, int* __restrict__ node_parent,
+                                                                 int* __restrict__ leaf_parent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T - 1) return;
+    const int d = common_prefix(keys, T, i, i + 1) - common_prefix(keys, T, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = common_prefix(keys, T, i, i - d);
+    int lmax = 2;
+    while (common_prefix(keys, T, i, i + lmax * d) > dmin && lmax < (1 << 30)) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (common_prefix(keys, T, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = common_prefix(keys, T, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (common_prefix(keys, T, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int lc = lo == gamma ? ~gamma : gamma;
+    const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    left[i] = lc;
+    right[i] = rc;
+    first[i] = lo;
+    last[i] = hi;
+    if (lc >= 0) node_parent[lc] = i; else leaf_parent[~lc] = i;
+    if (rc >= 0) node_parent[rc] = i; else leaf_parent[~rc] = i;
+    if (i == 0) node_parent[0] = -1;
+}
+
+// Read a value another workgroup wrote earlier in this launch (after the arrival-counter handshake): agent-scope load.
+__device__ __forceinline__ float coherent_load(const float* p)
+{
+    return __int_as_float(__hip_atomic_load(reinterpret_cast<int*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ int box_slot(int child, int T) { return child >= 0 ? child : (T - 1) + ~child; }
+
+// boxes: (2T - 1) x 6 floats, internal nodes first, then leaves by sorted position.
+__global__ __launch_bounds__(kBuildBlock) void fit_kernel(const FfTriangle* __restrict__ src, const uint32_t* __restrict__ vals, int T,
+                                                           const int* __restrict__ left, const int* __restrict__ right,
+                                                           const int* __restrict__ node_parent, const int* __restrict__ leaf_parent, float* boxes,
+                                                           int* arrivals)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const FfTriangle& t = src[vals[j]];
+    Box6 b = empty_box();
+    grow(b, t.m_v0);
+    grow(b, t.m_v1);
+    grow(b, t.m_v2);
+    float* mine = boxes + (size_t)((T - 1) + j) * 6;
+    for (int k = 0; k < 3; ++k) { mine[k] = b.mn[k]; mine[3 + k] = b.mx[k]; }
+    int cur = leaf_parent[j];
+    for (int guard = 0; guard < 4096; ++guard) { // a path to the root is at most 64 + 31 links long
+        __threadfence(); // publish the box written above before announcing it
+        const int earlier = atomicAdd(&arrivals[cur], 1);
+        if (earlier == 0) return; // the sibling subtree is not finished: its last thread completes this node
+        __threadfence(); // see the sibling's box
+        const float* lb = boxes + (size_t)box_slot(left[cur], T) * 6;
+        const float* rb = boxes + (size_t)box_slot(right[cur], T) * 6;
+        float* nb = boxes + (size_t)cur * 6;
+        for (int k = 0; k < 3; ++k) {
+            nb[k] = fminf(coherent_load(lb + k), coherent_load(rb + k));
+            nb[3 + k] = fmaxf(coherent_load(lb + 3 + k), coherent_load(rb + 3 + k));
+        }
+        if (cur == 0) return;
+        cur = node_parent[cur];
+    }
+}
+
+// Depth key of every internal node: its depth (root = 1) if it becomes a traversal node, kNotEmitted otherwise.
+__global__ __launch_bounds__(kBuildBlock) void rank_key_kernel(int T, int max_leaf, const int* __restrict__ first, const int* __restrict__ last,
+                                                                const int* __restrict__ node_parent, uint32_t* __restrict__ depth_key,
+                                                                uint32_t* __restrict__ ids, int* counters /* [0] emitted, [1] max depth */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T - 1) return;
+    ids[i] = (uint32_t)i;
+    if (last[i] - first[i] + 1 <= max_leaf) {
+        depth_key[i] = kNotEmitted;
+        return;
+    }
+    int depth = 1;
+    for (int p = node_parent[i]; p >= 0 && depth < 200; p = node_parent[p]) ++depth;
+    depth_key[i] = (uint32_t)depth;
+    atomicAdd(&counters[0], 1);
+    atomicMax(&counters[1], depth);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void rank_scatter_kernel(int n, const uint32_t* __restrict__ sorted_ids, int* __restrict__ new_index)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) new_index[sorted_ids[r]] = r;
+}
+
+__device__ __forceinline__ float mesh_pad(const int* bounds)
+{
+    // the host builder's padding (ff_scene.cpp): 1e-4 of the mesh's largest |coordinate|
+    float big = 0.0f;
+    for (int k = 0; k < 6; ++k) big = fmaxf(big, fabsf(ordered_float(bounds[k])));
+    return 1.0e-4f * fmaxf(big, 1.0e-3f);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void emit_kernel(int T, int emitted, int max_leaf, int tri_first, int node_base, const int* __restrict__ bounds,
+                                                            const uint32_t* __restrict__ sorted_ids, const int* __restrict__ new_index,
+                                                            const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
+                                                            const int* __restrict__ last, const float* __restrict__ boxes, BvhNode* __restrict__ nodes)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= emitted) return;
+    const int i = (int)sorted_ids[r];
+    const float pad = mesh_pad(bounds);
+    BvhNode nd;
+    nd.pad0 = 0;
+    nd.pad1 = 0;
+    const int child[2] = { left[i], right[i] };
+    int link[2];
+    for (int side = 0; side < 2; ++side) {
+        const int c = child[side];
+        const float* b = boxes + (size_t)box_slot(c, T) * 6;
+        float* mn = side == 0 ? nd.lmin : nd.rmin;
+        float* mx = side == 0 ? nd.lmax : nd.rmax;
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = b[k] - pad;
+            mx[k] = b[3 + k] + pad;
+        }
+        if (c < 0) {
+            link[side] = ~(((tri_first + ~c) << 3) | 0);
+        } else {
+            const int len = last[c] - first[c] + 1;
+            link[side] = len <= max_leaf ? ~(((tri_first + first[c]) << 3) | (len - 1)) : node_base + new_index[c];
+        }
+    }
+    nd.left = link[0];
+    nd.right = link[1];
+    nodes[node_base + r] = nd;
+}
+
+// The record of ff_scene.cpp's build_mesh_bvh, computed the same way (edges by one fp32 subtraction, margin in double).
+__device__ __forceinline__ void write_record(TriRecord& r, const FfTriangle& t, int orig_index)
+{
+    r.v0[0] = t.m_v0.x; r.v0[1] = t.m_v0.y; r.v0[2] = t.m_v0.z;
+    r.orig_index = orig_index;
+    const float e1[3] = { t.m_v1.x - t.m_v0.x, t.m_v1.y - t.m_v0.y, t.m_v1.z - t.m_v0.z };
+    const float e2[3] = { t.m_v2.x - t.m_v0.x, t.m_v2.y - t.m_v0.y, t.m_v2.z - t.m_v0.z };
+    for (int k = 0; k < 3; ++k) { r.e1[k] = e1[k]; r.e2[k] = e2[k]; }
+    const double m = ((double)fabsf(e1[0]) + (double)fabsf(e1[1]) + (double)fabsf(e1[2])) * ((double)fabsf(e2[0]) + (double)fabsf(e2[1]) + (double)fabsf(e2[2]));
+    const float f = (float)(32.0 * 5.9604644775390625e-8 * m);
+    r.cull_margin = __int_as_float(__float_as_int(f) + 1); // nextafter towards +inf for f >= 0
+    r.pad1 = 0;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void records_kernel(const FfTriangle* __restrict__ src, const uint32_t* __restrict__ vals, int T, int tri_first,
+                                                               TriRecord* __restrict__ tris)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const int orig = (int)vals[j];
+    TriRecord r;
+    write_record(r, src[orig], orig);
+    tris[tri_first + j] = r;
+}
+
+// ---- refit ------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBuildBlock) void refresh_records_kernel(const FfTriangle* __restrict__ src, int T, int tri_first, TriRecord* __restrict__ tris)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const int orig = tris[tri_first + j].orig_index;
+    if (orig < 0 || orig >= T) return; // never true for records this library wrote
+    TriRecord r;
+    write_record(r, src[orig], orig);
+    tris[tri_first + j] = r;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void link_parents_kernel(const BvhNode* __restrict__ nodes, int node_first, int node_count, int* __restrict__ parent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_count) return;
+    const BvhNode& nd = nodes[node_first + i];
+    const int l = nd.left, r = nd.right;
+    if (l >= 0 && l >= node_first && l < node_first + node_count) parent[l - node_first] = ((node_first + i) << 1) | 0;
+    if (r >= 0 && r >= node_first && r < node_first + node_count) parent[r - node_first] = ((node_first + i) << 1) | 1;
+}
+
+__device__ __forceinline__ void leaf_box(const FfTriangle* __restrict__ src, const TriRecord* __restrict__ tris, int link, float pad, float* mn, float* mx)
+{
+    const int ref = ~link, f = ref >> 3, count = (ref & 7) + 1;
+    Box6 b = empty_box();
+    for (int k = 0; k < count; ++k) {
+        const FfTriangle& t = src[tris[f + k].orig_index];
+        grow(b, t.m_v0);
+        grow(b, t.m_v1);
+        grow(b, t.m_v2);
+    }
+    for (int k = 0; k < 3; ++k) {
+        mn[k] = b.mn[k] - pad;
+        mx[k] = b.mx[k] + pad;
+    }
+}
+
+// One thread per inner node: write the boxes of its leaf children, then carry completed nodes upward.
+__global__ __launch_bounds__(kBuildBlock) void refit_kernel(const FfTriangle* __restrict__ src, const TriRecord* __restrict__ tris, const int* __restrict__ bounds,
+                                                             int node_first, int node_count, const int* __restrict__ parent, BvhNode* nodes, int* arrivals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_count) return;
+    const float pad = mesh_pad(bounds);
+    int n = node_first + i;
+    BvhNode* nd = nodes + n;
+    const int l = nd->left, r = nd->right;
+    int leaves = 0;
+    if (l < 0) { leaf_box(src, tris, l, pad, nd->lmin, nd->lmax); ++leaves; }
+    if (r < 0) { leaf_box(src, tris, r, pad, nd->rmin, nd->rmax); ++leaves; }
+    if (leaves == 0) return; // both boxes come from below
+    __threadfence();
+    if (atomicAdd(&arrivals[i], leaves) + leaves < 2) return;
+    for (int guard = 0; guard < 4096; ++guard) {
+        // node n is complete: both of its child boxes are final
+        __threadfence();
+        const int p = parent[n - node_first];
+        if (p < 0) return; // the root
+        const float* a = reinterpret_cast<const float*>(nodes + n);
+        float mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) {
+            // (the child boxes already carry the padding)
+            mn[k] = fminf(coherent_load(a + k), coherent_load(a + 8 + k));
+            mx[k] = fmaxf(coherent_load(a + 4 + k), coherent_load(a + 12 + k));
+        }
+        const int pn = p >> 1, side = p & 1;
+        BvhNode* pd = nodes + pn;
+        float* dmn = side == 0 ? pd->lmin : pd->rmin;
+        float* dmx = side == 0 ? pd->lmax : pd->rmax;
+        for (int k = 0; k < 3; ++k) { dmn[k] = mn[k]; dmx[k] = mx[k]; }
+        __threadfence();
+        if (atomicAdd(&arrivals[pn - node_first], 1) + 1 < 2) return;
+        n = pn;
+    }
+}
+
+// ---- scratch -----------------------------------------------------------------------------------------------------------
+
+struct Carver {
+    char* p;
+    size_t used = 0;
+    explicit Carver(void* base) : p(static_cast<char*>(base)) {}
+    template <class T>
+    T* take(size_t count)
+    {
+        used = (used + 255) & ~(size_t)255;
+        T* out = p ? reinterpret_cast<T*>(p + used) : nullptr;
+        used += count * sizeof(T);
+        return out;
+    }
+};
+
+int ensure_scratch(BuildScratch& s, size_t bytes)
+{
+    if (s.capacity >= bytes && s.base) return FF_OK;
+    if (s.base) (void)hipFree(s.base);
+    s.base = nullptr;
+    s.capacity = 0;
+    if (hipMalloc(&s.base, bytes) != hipSuccess) {
+        s.base = nullptr;
+        return fail(FF_ERR_OOM, "BVH builder: cannot allocate %zu bytes of device scratch", bytes);
+    }
+    s.capacity = bytes;
+    return FF_OK;
+}
+
+struct BuildBuffers {
+    int* bounds;
+    int* counters;
+    uint64_t *keys_in, *keys_out;
+    uint32_t *vals_in, *vals_out;
+    int *left, *right, *first, *last, *node_parent, *leaf_parent, *arrivals, *new_index;
+    float* boxes;
+    uint32_t *depth_in, *depth_out, *ids_in, *ids_out;
+    void* sort_temp;
+    size_t sort_temp_bytes;
+    size_t total;
+};
+
+BuildBuffers carve_build(void* base, int T, size_t sort_temp_bytes)
+{
+    Carver c(base);
+    BuildBuffers b;
+    const size_t n = (size_t)T, m = (size_t)(T > 1 ? T - 1 : 1);
+    b.bounds = c.take<int>(8);
+    b.counters = c.take<int>(8);
+    b.keys_in = c.take<uint64_t>(n);
+    b.keys_out = c.take<uint64_t>(n);
+    b.vals_in = c.take<uint32_t>(n);
+    b.vals_out = c.take<uint32_t>(n);
+    b.left = c.take<int>(m);
+    b.right = c.take<int>(m);
+    b.first = c.take<int>(m);
+    b.last = c.take<int>(m);
+    b.node_parent = c.take<int>(m);
+    b.leaf_parent = c.take<int>(n);
+    b.arrivals = c.take<int>(m);
+    b.new_index = c.take<int>(m);
+    b.boxes = c.take<float>((2 * n) * 6);
+    b.depth_in = c.take<uint32_t>(m);
+    b.depth_out = c.take<uint32_t>(m);
+    b.ids_in = c.take<uint32_t>(m);
+    b.ids_out = c.take<uint32_t>(m);
+    b.sort_temp = c.take<char>(sort_temp_bytes);
+    b.sort_temp_bytes = sort_temp_bytes;
+    b.total = c.used + 256;
+    return b;
+}
+
+} // namespace
+
+void free_build_scratch(BuildScratch& s)
+{
+    if (s.base) (void)hipFree(s.base);
+    s.base = nullptr;
+    s.capacity = 0;
+}
+
+int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int T, int tri_first, int node_base, int max_leaf,
+                   TriRecord* d_tris, BvhNode* d_nodes, MeshBuildInfo* out)
+{
+    if (T <= max_leaf || T < 2) return fail(FF_ERR_INVALID_ARG, "gpu_build_mesh: %d triangles fit one leaf", T);
+    if (max_leaf < 1 || max_leaf > 8) return fail(FF_ERR_INVALID_ARG, "max_leaf_tris must be 1..8");
+
+    // temporary storage of the two sorts (query with null storage)
+    size_t temp_codes = 0, temp_depth = 0;
+    FFB_HIP(rocprim::radix_sort_pairs(nullptr, temp_codes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)T, 0u, 63u,
+                                      stream));
+    FFB_HIP(rocprim::radix_sort_pairs(nullptr, temp_depth, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(T - 1), 0u,
+                                      8u, stream));
+    const size_t sort_temp = temp_codes > temp_depth ? temp_codes : temp_depth;
+    const BuildBuffers sizes = carve_build(nullptr, T, sort_temp);
+    int st = ensure_scratch(scratch, sizes.total);
+    if (st != FF_OK) return st;
+    const BuildBuffers b = carve_build(scratch.base, T, sort_temp);
+
+    const int tri_grid = grid_for(T), node_grid = grid_for(T - 1);
+    init_bounds_kernel<<<1, 64, 0, stream>>>(b.bounds);
+    FFB_HIP(hipMemsetAsync(b.counters, 0, 8 * sizeof(int), stream));
+    FFB_HIP(hipMemsetAsync(b.arrivals, 0, (size_t)(T - 1) * sizeof(int), stream));
+    bounds_kernel<<<tri_grid < 1024 ? tri_grid : 1024, kBuildBlock, 0, stream>>>(d_src, T, b.bounds);
+    morton_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, T, b.bounds, b.keys_in, b.vals_in);
+    size_t tb = b.sort_temp_bytes;
+    FFB_HIP(rocprim::radix_sort_pairs(b.sort_temp, tb, b.keys_in, b.keys_out, b.vals_in, b.vals_out, (size_t)T, 0u, 63u, stream));
+    hierarchy_kernel<<<node_grid, kBuildBlock, 0, stream>>>(b.keys_out, T, b.left, b.right, b.first, b.last, b.node_parent, b.leaf_parent);
+    fit_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, b.left, b.right, b.node_parent, b.leaf_parent, b.boxes, b.arrivals);
+    rank_key_kernel<<<node_grid, kBuildBlock, 0, stream>>>(T, max_leaf, b.first, b.last, b.node_parent, b.depth_in, b.ids_in, b.counters);
+    tb = b.sort_temp_bytes;
+    FFB_HIP(rocprim::radix_sort_pairs(b.sort_temp, tb, b.depth_in, b.depth_out, b.ids_in, b.ids_out, (size_t)(T - 1), 0u, 8u, stream));
+    int host_counters[2] = { 0, 0 };
+    FFB_HIP(hipMemcpyAsync(host_counters, b.counters, sizeof host_counters, hipMemcpyDeviceToHost, stream));
+    FFB_HIP(hipStreamSynchronize(stream));
+    const int emitted = host_counters[0], depth = host_counters[1];
+    if (emitted < 1 || emitted > T - 1) return fail(FF_ERR_HIP, "gpu_build_mesh: inconsistent node count %d for %d triangles", emitted, T);
+    if (depth >= (int)kNotEmitted) return fail(FF_ERR_UNSUPPORTED, "gpu_build_mesh: tree depth %d exceeds the builder's limit", depth);
+    rank_scatter_kernel<<<grid_for(emitted), kBuildBlock, 0, stream>>>(emitted, b.ids_out, b.new_index);
+    emit_kernel<<<grid_for(emitted), kBuildBlock, 0, stream>>>(T, emitted, max_leaf, tri_first, node_base, b.bounds, b.ids_out, b.new_index, b.left, b.right,
+                                                               b.first, b.last, b.boxes, d_nodes);
+    records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, tri_first, d_tris);
+    FFB_HIP(hipGetLastError());
+    out->root = node_base;
+    out->node_count = emitted;
+    out->depth = depth;
+    return FF_OK;
+}
+
+int gpu_link_parents(hipStream_t stream, const BvhNode* d_nodes, int node_first, int node_count, int* d_parent)
+{
+    if (node_count <= 0) return FF_OK;
+    FFB_HIP(hipMemsetAsync(d_parent, 0xff, (size_t)node_count * sizeof(int), stream));
+    link_parents_kernel<<<grid_for(node_count), kBuildBlock, 0, stream>>>(d_nodes, node_first, node_count, d_parent);
+    FFB_HIP(hipGetLastError());
+    return FF_OK;
+}
+
+int gpu_refit_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int T, int tri_first, int node_first, int node_count,
+                   const int* d_parent, TriRecord* d_tris, BvhNode* d_nodes)
+{
+    if (T <= 0 || node_count <= 0) return FF_OK;
+    Carver probe(nullptr);
+    probe.take<int>(8);
+    probe.take<int>((size_t)node_count);
+    int st = ensure_scratch(scratch, probe.used + 256);
+    if (st != FF_OK) return st;
+    Carver c(scratch.base);
+    int* bounds = c.take<int>(8);
+    int* arrivals = c.take<int>((size_t)node_count);
+    init_bounds_kernel<<<1, 64, 0, stream>>>(bounds);
+    FFB_HIP(hipMemsetAsync(arrivals, 0, (size_t)node_count * sizeof(int), stream));
+    const int tri_grid = grid_for(T);
+    bounds_kernel<<<tri_grid < 1024 ? tri_grid : 1024, kBuildBlock, 0, stream>>>(d_src, T, bounds);
+    refresh_records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, T, tri_first, d_tris);
+    refit_kernel<<<grid_for(node_count), kBuildBlock, 0, stream>>>(d_src, d_tris, bounds, node_first, node_count, d_parent, d_nodes, arrivals);
+    FFB_HIP(hipGetLastError());
+    return FF_OK;
+}
+
+} // namespace ff

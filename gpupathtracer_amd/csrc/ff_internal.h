@@ -91,7 +91,11 @@ BvhBuildParams default_bvh_params();
 int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams& params, std::vector<BvhNode>& nodes,
                    std::vector<TriRecord>& tris, int* out_depth);
 
-// Flatten host geometries into device records.  Returns an FfStatus.
-int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out);
+// Flatten host geometries into device records.  Returns an FfStatus.  build_bvh = false fills the geometry records only
+// (tri_first / tri_count assigned, bvh_root = -1, no triangle records, no nodes): the device builder's input.
+int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out, bool build_bvh = true);
+
+// World-space AABB of a geometry record from object-space bounds (through the record's model matrix, padded).
+void set_world_box(GeomRecord& r, const float omn[3], const float omx[3]);
 
 } // namespace ff

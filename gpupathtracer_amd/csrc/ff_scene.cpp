@@ -298,7 +298,33 @@ int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams&
     return node_base;
 }
 
-int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out)
+// World-space AABB of a geometry from its object-space bounds (pruning only): the eight corners through the model matrix,
+// padded.  An empty object box (omn > omx) gives a box no ray can enter.
+void set_world_box(GeomRecord& r, const float omn[3], const float omx[3])
+{
+    using namespace ffm;
+    M4 mod;
+    mod.c[0] = v4(r.mod_c0[0], r.mod_c0[1], r.mod_c0[2], 0.f);
+    mod.c[1] = v4(r.mod_c1[0], r.mod_c1[1], r.mod_c1[2], 0.f);
+    mod.c[2] = v4(r.mod_c2[0], r.mod_c2[1], r.mod_c2[2], 0.f);
+    mod.c[3] = v4(r.mod_c3[0], r.mod_c3[1], r.mod_c3[2], 1.f);
+    Box wb;
+    wb.reset();
+    if (omn[0] <= omx[0]) {
+        for (int c = 0; c < 8; ++c) {
+            const V4 pw = mul(mod, v4((c & 1) ? omx[0] : omn[0], (c & 2) ? omx[1] : omn[1], (c & 4) ? omx[2] : omn[2], 1.f));
+            wb.grow(&pw.x);
+        }
+        float big = 0.f;
+        for (int k = 0; k < 3; ++k) big = std::max(big, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + (wb.mx[k] - wb.mn[k]));
+        const float wpad = 1e-4f * big + 1e-4f;
+        for (int k = 0; k < 3; ++k) { r.wmin[k] = wb.mn[k] - wpad; r.wmax[k] = wb.mx[k] + wpad; }
+    } else {
+        for (int k = 0; k < 3; ++k) { r.wmin[k] = 3.0e38f; r.wmax[k] = 3.0e38f; }
+    }
+}
+
+int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out, bool build_bvh)
 {
     using namespace ffm;
     out = CompiledScene();
@@ -350,30 +376,20 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
             }
             for (int k = 0; k < 3; ++k) { omn[k] = ob.mn[k]; omx[k] = ob.mx[k]; }
         }
-        Box wb;
-        wb.reset();
-        if (omn[0] <= omx[0]) {
-            for (int c = 0; c < 8; ++c) {
-                const V4 pw = mul(mod, v4((c & 1) ? omx[0] : omn[0], (c & 2) ? omx[1] : omn[1], (c & 4) ? omx[2] : omn[2], 1.f));
-                wb.grow(&pw.x);
-            }
-            float big = 0.f;
-            for (int k = 0; k < 3; ++k) big = std::max(big, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + (wb.mx[k] - wb.mn[k]));
-            const float wpad = 1e-4f * big + 1e-4f;
-            for (int k = 0; k < 3; ++k) { r.wmin[k] = wb.mn[k] - wpad; r.wmax[k] = wb.mx[k] + wpad; }
-        } else { // empty mesh: a box no ray can enter
-            for (int k = 0; k < 3; ++k) { r.wmin[k] = 3.0e38f; r.wmax[k] = 3.0e38f; }
-        }
+        set_world_box(r, omn, omx);
         if (g.m_geometryType == FF_GEOM_TRIANGLEMESH) {
             const int cnt = g.m_triangles ? g.m_numberOfTriangles : 0;
             if (cnt < 0) return fail(FF_ERR_INVALID_ARG, "geometry %d: negative triangle count", i);
             if ((uint64_t)out.tris.size() + (uint64_t)cnt >= (1ull << 28))
                 return fail(FF_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles");
-            r.tri_first = (int)out.tris.size();
+            if ((uint64_t)out.total_tris + (uint64_t)cnt >= (1ull << 28)) return fail(FF_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles");
+            r.tri_first = (int)out.total_tris;
             r.tri_count = cnt;
-            int depth = 0;
-            r.bvh_root = build_mesh_bvh(g.m_triangles, cnt, params, out.nodes, out.tris, &depth);
-            out.max_depth = std::max(out.max_depth, depth);
+            if (build_bvh) {
+                int depth = 0;
+                r.bvh_root = build_mesh_bvh(g.m_triangles, cnt, params, out.nodes, out.tris, &depth);
+                out.max_depth = std::max(out.max_depth, depth);
+            }
             out.total_tris += (uint64_t)cnt;
         }
     }

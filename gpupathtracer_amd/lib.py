@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libfirefly_hip.so")
 EXPORTS = [
     "ff_create", "ff_destroy", "ff_last_error", "ff_version", "ff_set_stream",
     "ff_geometry_init", "ff_bxdf_init", "ff_camera_init_default", "ff_camera_update_basis", "ff_camera_ray_matrix",
-    "ff_upload_scene", "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
+    "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh",
+    "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
@@ -61,6 +62,11 @@ def load():
     lib.ff_camera_ray_matrix.argtypes = [P(T.FfCamera), P(T.FfMat4)]
     lib.ff_camera_ray_matrix.restype = None
     lib.ff_upload_scene.argtypes = [vp, P(T.FfGeometry), i32]
+    lib.ff_set_builder.argtypes = [vp, i32]
+    lib.ff_update_transforms.argtypes = [vp, P(T.FfGeometry), i32]
+    lib.ff_update_mesh.argtypes = [vp, i32, P(T.FfTriangle), i32, i32]
+    lib.ff_build_stats.argtypes = [vp, P(T.FfBuildStats)]
+    lib.ff_debug_download_bvh.argtypes = [vp, vp, i32, P(i32), vp, i32, P(i32), P(i32), i32]
     lib.ff_scene_info.argtypes = [P(T.FfGeometry), i32, P(T.FfSceneInfo)]
     lib.ff_render.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), vp, i32, vp, i32]
     lib.ff_render_strips.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, i32, i32, vp, i32, vp, i32, P(i32)]
@@ -185,6 +191,36 @@ class Tracer:
     def upload_scene(self, scene):
         """scene: gpupathtracer_amd.scenes.Scene"""
         check(self._lib.ff_upload_scene(self._state, scene.geometries, len(scene)))
+
+    def set_builder(self, builder):
+        """T.BUILD_HOST_SAH (default) or T.BUILD_GPU_LBVH for the following upload_scene calls."""
+        check(self._lib.ff_set_builder(self._state, builder))
+
+    def update_transforms(self, scene):
+        """Same geometries as uploaded, new transforms / materials: rewrites the per-geometry records only."""
+        check(self._lib.ff_update_transforms(self._state, scene.geometries, len(scene)))
+
+    def update_mesh(self, geometry_index, triangles, mode=T.UPDATE_REFIT):
+        """New vertices (float32 [n, 24], as load_obj returns) for one uploaded mesh: refit or rebuild its tree on the device."""
+        buf = T.triangles_from_array(triangles)
+        check(self._lib.ff_update_mesh(self._state, geometry_index, buf, len(buf), mode))
+
+    def build_stats(self):
+        st = T.FfBuildStats()
+        check(self._lib.ff_build_stats(self._state, C.byref(st)))
+        return st
+
+    def download_bvh(self, num_geometries):
+        """(nodes, triangle records, mesh table) of the compiled scene (tests).  mesh table: int32 [num_geometries, 5] =
+        bvh_root, node_count, tri_first, tri_count, depth per uploaded geometry."""
+        nn, nt = C.c_int(0), C.c_int(0)
+        check(self._lib.ff_debug_download_bvh(self._state, None, 0, C.byref(nn), None, 0, C.byref(nt), None, 0))
+        nodes = np.zeros(max(nn.value, 1), dtype=T.BVH_NODE_DTYPE)
+        tris = np.zeros(max(nt.value, 1), dtype=T.TRI_RECORD_DTYPE)
+        table = np.full((num_geometries, 5), -1, dtype=np.int32)
+        check(self._lib.ff_debug_download_bvh(self._state, nodes.ctypes.data, nn.value, C.byref(nn), tris.ctypes.data, nt.value, C.byref(nt),
+                                              table.ctypes.data_as(C.POINTER(C.c_int)), num_geometries))
+        return nodes[:nn.value], tris[:nt.value], table
 
     def set_collect_stats(self, on):
         check(self._lib.ff_set_collect_stats(self._state, 1 if on else 0))

@@ -108,6 +108,25 @@ class FfStats(C.Structure):
     ]
 
 
+class FfBuildStats(C.Structure):
+    _fields_ = [
+        ("builder", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_max_depth", C.c_int32), ("last_operation", C.c_int32),
+        ("num_triangles", C.c_uint64), ("total_ms", C.c_double), ("copy_ms", C.c_double), ("build_ms", C.c_double),
+    ]
+
+
+BUILD_HOST_SAH, BUILD_GPU_LBVH = 0, 1
+UPDATE_REFIT, UPDATE_REBUILD = 0, 1
+
+# device records as ff_debug_download_bvh returns them (gpupathtracer_amd/csrc/ff_internal.h)
+import numpy as _np
+BVH_NODE_DTYPE = _np.dtype([("lmin", _np.float32, 3), ("left", _np.int32), ("lmax", _np.float32, 3), ("right", _np.int32),
+                            ("rmin", _np.float32, 3), ("pad0", _np.int32), ("rmax", _np.float32, 3), ("pad1", _np.int32)])
+TRI_RECORD_DTYPE = _np.dtype([("v0", _np.float32, 3), ("orig_index", _np.int32), ("e1", _np.float32, 3), ("cull_margin", _np.float32),
+                              ("e2", _np.float32, 3), ("pad1", _np.int32)])
+assert BVH_NODE_DTYPE.itemsize == 64 and TRI_RECORD_DTYPE.itemsize == 48
+
+
 class FfSceneInfo(C.Structure):
     _fields_ = [
         ("num_geometries", C.c_int32), ("num_meshes", C.c_int32), ("num_planes", C.c_int32),

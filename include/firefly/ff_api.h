@@ -93,6 +93,31 @@ FF_API void ff_camera_ray_matrix(const FfCamera* c, FfMat4* out_inv_view_times_i
  * SPHERE geometries are rejected with FF_ERR_UNSUPPORTED. */
 FF_API int ff_upload_scene(FfState* state, const FfGeometry* host_geometries, int n);
 
+/* ---- dynamic scenes (no counterpart in the reference, whose upload is one-off) ------- */
+
+/* Selects the BVH builder used by the following ff_upload_scene calls (default FF_BUILD_HOST_SAH).  Rendered results do
+ * not depend on the builder: every hit is decided by the reference arithmetic, the tree only prunes. */
+FF_API int ff_set_builder(FfState* state, int builder);
+
+/* The same geometries as the last upload (same count, types and triangle counts) with new transforms / materials:
+ * rewrites the per-geometry records only.  Trees live in object space, so moving, rotating or scaling a mesh costs no
+ * rebuild. */
+FF_API int ff_update_transforms(FfState* state, const FfGeometry* host_geometries, int n);
+
+/* New vertex positions for mesh `geometry_index` (index in the uploaded Geometry array; `count` must equal the uploaded
+ * triangle count).  FF_UPDATE_REFIT keeps the tree and recomputes its boxes on the device; FF_UPDATE_REBUILD builds a
+ * new tree on the device in the mesh's slot. */
+FF_API int ff_update_mesh(FfState* state, int geometry_index, const FfTriangle* triangles, int count, int mode);
+
+FF_API int ff_build_stats(FfState* state, FfBuildStats* out_stats);
+
+/* Copies the compiled scene back for inspection (tests): up to `max_nodes` 64-byte nodes and `max_tris` 48-byte triangle
+ * records; the counts in use are returned through out_nodes / out_tris.  mesh_table (optional) receives, for each of the
+ * first `max_geometries` uploaded geometries in the caller's order, {bvh_root, node_count, tri_first, tri_count, depth}
+ * (bvh_root = -1 for planes and empty meshes).  Buffers may be null to query the counts. */
+FF_API int ff_debug_download_bvh(FfState* state, void* nodes, int max_nodes, int* out_nodes, void* tris, int max_tris, int* out_tris,
+                                 int* mesh_table, int max_geometries);
+
 /* Host-only dry run of the scene compiler: sizes, BVH shape and a structural self-check.  Needs no GPU. */
 FF_API int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneInfo* out_info);
 

@@ -169,6 +169,30 @@ typedef struct FfStats {
     uint64_t scene_bytes_tris;   /* device bytes of triangle records */
 } FfStats;
 
+/* Which builder produces the BVH (ff_set_builder). */
+typedef enum FfBuilder {
+    FF_BUILD_HOST_SAH = 0, /* binned SAH on the host: best trees, for scenes uploaded once (the reference's case, kernel.cu:268-298) */
+    FF_BUILD_GPU_LBVH = 1  /* Morton-code LBVH built on the device: for geometry that changes between frames */
+} FfBuilder;
+
+/* ff_update_mesh modes. */
+typedef enum FfMeshUpdate {
+    FF_UPDATE_REFIT   = 0, /* keep the tree, recompute its boxes from the moved vertices */
+    FF_UPDATE_REBUILD = 1  /* rebuild the mesh's tree on the device (scene must have been uploaded with FF_BUILD_GPU_LBVH) */
+} FfMeshUpdate;
+
+/* Filled by ff_build_stats(): the last ff_upload_scene / ff_update_mesh / ff_update_transforms call. */
+typedef struct FfBuildStats {
+    int32_t  builder;          /* FfBuilder that produced the current trees */
+    int32_t  bvh_nodes;        /* 64-byte inner nodes in use over all meshes */
+    int32_t  bvh_max_depth;    /* deepest root-to-leaf path, in inner nodes */
+    int32_t  last_operation;   /* 0 upload, 1 refit, 2 rebuild, 3 transforms */
+    uint64_t num_triangles;
+    double   total_ms;         /* host wall clock of the whole call */
+    double   copy_ms;          /* of which: host-to-device copies of the caller's triangles */
+    double   build_ms;         /* of which: tree construction / refit (host builder: on the CPU; device builder: kernels, synchronised) */
+} FfBuildStats;
+
 /* Filled by ff_scene_info(): what ff_upload_scene would build for a host scene (no GPU needed). */
 typedef struct FfSceneInfo {
     int32_t  num_geometries;

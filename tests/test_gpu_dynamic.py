@@ -1,0 +1,283 @@
+"""GPU tests of the dynamic-scene row: BVHs built on the device (LBVH), refitted in place and
+re-based by transform updates.  The bar is the parity bar of test_gpu_parity.py: whichever tree the device holds, the
+frames must equal the oracle's golden frames bit for bit — plus structural checks of the trees themselves.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cases import CASES, POSES, build_case
+from gpupathtracer_amd import lib, scenes
+from gpupathtracer_amd import types as T
+from oracle_lib import oracle_render
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.fixture()
+def lbvh_tracer():
+    with lib.Tracer(0) as t:
+        t.set_builder(T.BUILD_GPU_LBVH)
+        yield t
+
+
+def same_bits(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def check_tree(nodes, tris, table, max_leaf=4):
+    """Every mesh: its inner nodes form one tree under the root (each reached exactly once, level by level), all of its
+    triangles sit in exactly one leaf, every child box encloses what is below it, node count and depth as reported.
+    Vectorised so that the million-triangle tree is checked in seconds.  Returns the number of inner nodes walked."""
+    walked = 0
+    v0 = tris["v0"].astype(np.float64)
+    verts = np.stack([v0, v0 + tris["e1"], v0 + tris["e2"]], axis=1)  # [n, 3, 3]
+    tmin, tmax = verts.min(axis=1), verts.max(axis=1)
+    for root, node_count, tri_first, tri_count, depth in table:
+        if root < 0:
+            continue
+        slot = nodes[root:root + node_count]
+        links = np.stack([slot["left"], slot["right"]], axis=1).astype(np.int64)       # [n, 2]
+        cmin = np.stack([slot["lmin"], slot["rmin"]], axis=1).astype(np.float64)       # [n, 2, 3]
+        cmax = np.stack([slot["lmax"], slot["rmax"]], axis=1).astype(np.float64)
+        inner = links >= 0
+        assert ((links[inner] >= root) & (links[inner] < root + node_count)).all(), "inner link outside the mesh slot"
+        # reachability, level by level
+        seen_node = np.zeros(node_count, dtype=np.int32)
+        frontier = np.array([0], dtype=np.int64)
+        levels = 0
+        while frontier.size:
+            levels += 1
+            assert levels <= 256
+            np.add.at(seen_node, frontier, 1)
+            nxt = links[frontier]
+            frontier = nxt[nxt >= 0] - root
+        assert (seen_node == 1).all(), f"{(seen_node != 1).sum()} nodes are not reached exactly once from the root"
+        assert levels <= depth, (levels, depth)
+        # leaves: coverage and box enclosure
+        single = node_count == 1 and links[0, 0] == links[0, 1]
+        ref = ~links
+        lf, lc = ref >> 3, (ref & 7) + 1
+        leaf = ~inner
+        if single:
+            leaf = leaf.copy()
+            leaf[0, 1] = False  # a one-leaf mesh lists its leaf on both sides (tested twice, harmless)
+        assert (lc[leaf] <= max_leaf).all()
+        assert ((lf[leaf] >= tri_first) & (lf[leaf] + lc[leaf] <= tri_first + tri_count)).all(), "leaf outside the mesh's triangle range"
+        cover = np.zeros(tri_count + 1, dtype=np.int64)
+        np.add.at(cover, lf[leaf] - tri_first, 1)
+        np.add.at(cover, lf[leaf] + lc[leaf] - tri_first, -1)
+        assert (np.cumsum(cover)[:-1] == 1).all(), "some triangles are not in exactly one leaf"
+        sub_min = np.full((node_count, 2, 3), np.inf)
+        sub_max = np.full((node_count, 2, 3), -np.inf)
+        allleaf = ~inner
+        for k in range(max_leaf):
+            m = allleaf & (lc > k)
+            idx = lf[m] + k
+            sub_min[m] = np.minimum(sub_min[m], tmin[idx])
+            sub_max[m] = np.maximum(sub_max[m], tmax[idx])
+        # inner children: the union of the child node's two boxes (already padded) must lie inside the parent's slot,
+        # up to the padding's own rounding
+        own_min, own_max = cmin.min(axis=1), cmax.max(axis=1)
+        child = links[inner] - root
+        sub_min[inner] = own_min[child]
+        sub_max[inner] = own_max[child]
+        tol = 1e-6 * max(1.0, float(np.abs(tmin[tri_first:tri_first + tri_count]).max()), float(np.abs(tmax[tri_first:tri_first + tri_count]).max()))
+        assert (cmin <= sub_min + tol).all() and (cmax >= sub_max - tol).all(), "a child box does not enclose its subtree"
+        orig = np.sort(tris["orig_index"][tri_first:tri_first + tri_count])
+        assert np.array_equal(orig, np.arange(tri_count)), "triangle records are not a permutation of the mesh"
+        walked += node_count
+    return walked
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_frames_with_device_built_trees(lbvh_tracer, golden, name):
+    scene, cam, params = build_case(name)
+    lbvh_tracer.upload_scene(scene)
+    bs = lbvh_tracer.build_stats()
+    assert bs.builder == T.BUILD_GPU_LBVH and bs.num_triangles == scene.triangle_count
+    rgb8, rad = lbvh_tracer.render(cam, params)
+    assert np.array_equal(rgb8, golden[name + "/rgb8"]), f"{name}: {(rgb8 != golden[name + '/rgb8']).any(axis=2).sum()} pixels differ"
+    assert same_bits(rad, golden[name + "/radiance"]), f"{name}: radiance not bit-identical"
+
+
+@pytest.mark.parametrize("mesh", ["cube", "sphere", "sphereBlender", "wahoo", "rocketman"])
+def test_device_built_tree_structure(lbvh_tracer, mesh):
+    scene = scenes.reference_scene(scenes.load_mesh(mesh))
+    lbvh_tracer.upload_scene(scene)
+    nodes, tris, table = lbvh_tracer.download_bvh(len(scene))
+    walked = check_tree(nodes, tris, table)
+    bs = lbvh_tracer.build_stats()
+    assert walked >= 1 and bs.bvh_max_depth >= 1
+    # the records are the host compiler's records (same arithmetic), only the order differs
+    with lib.Tracer(0) as host:
+        host.upload_scene(scene)
+        _, htris, _ = host.download_bvh(len(scene))
+    key = np.argsort(tris["orig_index"], kind="stable")
+    hkey = np.argsort(htris["orig_index"], kind="stable")
+    assert np.array_equal(tris[key].view(np.uint8), htris[hkey].view(np.uint8))
+
+
+def test_host_built_tree_structure(tracer):
+    scene = scenes.cornell_wahoo_scene()
+    tracer.upload_scene(scene)
+    check_tree(*tracer.download_bvh(len(scene)))
+
+
+def test_duplicate_centroids_and_degenerate_extent(lbvh_tracer):
+    """Identical Morton codes (coincident triangles) and a mesh that is flat in one axis must still give a well-formed tree."""
+    tri = np.zeros((1, 24), dtype=np.float32)
+    tri[0, 0:9] = [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    flat = np.repeat(tri, 37, axis=0)          # 37 coincident triangles in the z = 0 plane
+    flat[20:, 0:9:3] += 2.0                    # ... and a second coincident pile shifted in x
+    scene = scenes.reference_scene(flat)
+    lbvh_tracer.upload_scene(scene)
+    check_tree(*lbvh_tracer.download_bvh(len(scene)))
+
+
+def _with_mesh(scene, geometry_index, triangles=None, position=None, rotation=None, scale=None):
+    out = scenes.Scene()
+    for i, (kind, pos, rot, scl, tris, bxdf) in enumerate(scene._specs):
+        if i == geometry_index:
+            tris = tris if triangles is None else np.asarray(triangles, dtype=np.float32)
+            pos = pos if position is None else position
+            rot = rot if rotation is None else rotation
+            scl = scl if scale is None else scale
+        out._specs.append((kind, pos, rot, scl, tris, bxdf))
+    return out.finalize()
+
+
+def _mesh_index(scene, which=0):
+    idx = [i for i, s in enumerate(scene._specs) if s[0] == T.GEOM_TRIANGLEMESH]
+    return idx[which]
+
+
+def _deform(triangles, phase):
+    """A smooth, clearly visible deformation of a mesh (vertex positions only)."""
+    out = np.array(triangles, dtype=np.float32, copy=True)
+    for v in range(3):
+        x, y, z = out[:, 3 * v], out[:, 3 * v + 1], out[:, 3 * v + 2]
+        out[:, 3 * v] = (x + 0.35 * np.sin(1.3 * y + phase)).astype(np.float32)
+        out[:, 3 * v + 2] = (z * (1.0 + 0.25 * np.cos(0.7 * y + phase))).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH], ids=["host_tree", "device_tree"])
+@pytest.mark.parametrize("mode", [T.UPDATE_REFIT, T.UPDATE_REBUILD], ids=["refit", "rebuild"])
+def test_update_mesh_matches_fresh_upload_and_oracle(builder, mode):
+    scene = scenes.cornell_wahoo_scene()
+    gi = _mesh_index(scene, 0)
+    moved = _deform(scene._specs[gi][4], phase=0.6)
+    scene2 = _with_mesh(scene, gi, triangles=moved)
+    cam = scenes.posed_camera(72, 54, **POSES["default"])
+    params = lib.render_params(72, 54, 4, 2, 99, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+    with lib.Tracer(0) as t:
+        t.set_builder(builder)
+        t.upload_scene(scene)
+        if mode == T.UPDATE_REBUILD and builder == T.BUILD_HOST_SAH:
+            with pytest.raises(lib.FireflyError) as e:
+                t.update_mesh(gi, moved, mode)
+            assert e.value.status == T.FF_ERR_UNSUPPORTED
+            return
+        before = t.render(cam, params)[1]
+        t.update_mesh(gi, moved, mode)
+        bs = t.build_stats()
+        assert bs.last_operation == (1 if mode == T.UPDATE_REFIT else 2)
+        check_tree(*t.download_bvh(len(scene)))
+        rgb8, rad = t.render(cam, params)
+    with lib.Tracer(0) as fresh:
+        fresh.upload_scene(scene2)
+        rgb8_f, rad_f = fresh.render(cam, params)
+    assert not same_bits(before, rad), "the deformation should change the image"
+    assert np.array_equal(rgb8, rgb8_f) and same_bits(rad, rad_f)
+    o_rgb8, o_rad = oracle_render(scene2, cam, params)
+    assert np.array_equal(rgb8, o_rgb8) and same_bits(rad, o_rad)
+
+
+def test_refit_twice_then_rebuild(lbvh_tracer):
+    """A tree refitted over several frames and finally rebuilt keeps giving the frames of a fresh upload."""
+    scene = scenes.blooper_scene()
+    gi = _mesh_index(scene, 0)
+    base = scene._specs[gi][4]
+    cam = scenes.posed_camera(64, 64, **POSES["oblique"])
+    params = lib.render_params(64, 64, 3, 2, 5, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+    lbvh_tracer.upload_scene(scene)
+    for step, mode in enumerate([T.UPDATE_REFIT, T.UPDATE_REFIT, T.UPDATE_REBUILD, T.UPDATE_REFIT]):
+        moved = _deform(base, phase=0.4 * (step + 1))
+        lbvh_tracer.update_mesh(gi, moved, mode)
+        check_tree(*lbvh_tracer.download_bvh(len(scene)))
+        rad = lbvh_tracer.render(cam, params)[1]
+        with lib.Tracer(0) as fresh:
+            fresh.upload_scene(_with_mesh(scene, gi, triangles=moved))
+            assert same_bits(rad, fresh.render(cam, params)[1]), f"step {step}"
+
+
+@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH], ids=["host_tree", "device_tree"])
+def test_update_transforms_matches_fresh_upload(builder):
+    scene = scenes.cornell_wahoo_scene()
+    gi = _mesh_index(scene, 0)
+    scene2 = _with_mesh(scene, gi, position=(0.6, -2.2, -0.4), rotation=(0.0, 35.0, 10.0), scale=(0.22, 0.3, 0.25))
+    cam = scenes.posed_camera(72, 54, **POSES["default"])
+    params = lib.render_params(72, 54, 4, 2, 3, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+    with lib.Tracer(0) as t:
+        t.set_builder(builder)
+        t.upload_scene(scene)
+        before = t.render(cam, params)[1]
+        t.update_transforms(scene2)
+        assert t.build_stats().last_operation == 3
+        rgb8, rad = t.render(cam, params)
+    o_rgb8, o_rad = oracle_render(scene2, cam, params)
+    assert not same_bits(before, rad)
+    assert np.array_equal(rgb8, o_rgb8) and same_bits(rad, o_rad)
+
+
+def test_update_errors(tracer):
+    scene = scenes.cornell_wahoo_scene()
+    gi = _mesh_index(scene, 0)
+    tris = scene._specs[gi][4]
+    with lib.Tracer(0) as t:
+        with pytest.raises(lib.FireflyError) as e:
+            t.update_mesh(gi, tris)
+        assert e.value.status == T.FF_ERR_NO_SCENE
+        with pytest.raises(lib.FireflyError) as e:
+            t.update_transforms(scene)
+        assert e.value.status == T.FF_ERR_NO_SCENE
+        with pytest.raises(lib.FireflyError) as e:
+            t.set_builder(7)
+        assert e.value.status == T.FF_ERR_INVALID_ARG
+        t.upload_scene(scene)
+        with pytest.raises(lib.FireflyError) as e:
+            t.update_mesh(gi, tris[:-1])
+        assert e.value.status == T.FF_ERR_INVALID_ARG
+        plane = [i for i, s in enumerate(scene._specs) if s[0] == T.GEOM_PLANE][0]
+        with pytest.raises(lib.FireflyError) as e:
+            t.update_mesh(plane, tris)
+        assert e.value.status == T.FF_ERR_INVALID_ARG
+        with pytest.raises(lib.FireflyError) as e:
+            t.update_transforms(scenes.blooper_scene())
+        assert e.value.status == T.FF_ERR_INVALID_ARG
+
+
+def test_million_triangle_device_build(lbvh_tracer):
+    """BASELINE config 4 (983 040 triangles): device build, structure, and the same frame as the host-built tree."""
+    scene = scenes.sphere_stress_scene(5)
+    lbvh_tracer.upload_scene(scene)
+    bs = lbvh_tracer.build_stats()
+    assert bs.num_triangles == scene.triangle_count >= 983040
+    nodes, tris, table = lbvh_tracer.download_bvh(len(scene))
+    check_tree(nodes, tris, table)
+    cam = scenes.posed_camera(160, 90, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    params = lib.render_params(160, 90, 4, 2, 11, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+    rgb8, rad = lbvh_tracer.render(cam, params)
+    with lib.Tracer(0) as host:
+        host.upload_scene(scene)
+        rgb8_h, rad_h = host.render(cam, params)
+    assert np.array_equal(rgb8, rgb8_h) and same_bits(rad, rad_h)
