@@ -51,6 +51,14 @@ struct FfState {
     size_t rgb8_bytes = 0;
     float* d_radiance = nullptr;
     size_t radiance_bytes = 0;
+    // progressive accumulation (ff_render_progressive)
+    float* d_accum = nullptr;
+    size_t accum_bytes = 0;
+    float* d_frame = nullptr;
+    size_t frame_bytes = 0;
+    float* d_mean = nullptr;
+    size_t mean_bytes = 0;
+    int accum_width = 0, accum_height = 0, accum_frames = 0;
     unsigned* d_queue = nullptr;
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -300,6 +308,9 @@ int ff_destroy(FfState* s)
     if (s->pbo_resource) (void)hipGraphicsUnregisterResource(s->pbo_resource);
     free_scene(s);
     if (s->d_stage) (void)hipFree(s->d_stage);
+    if (s->d_accum) (void)hipFree(s->d_accum);
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    if (s->d_mean) (void)hipFree(s->d_mean);
     free_build_scratch(s->scratch);
     if (s->d_blocksums) (void)hipFree(s->d_blocksums);
     if (s->d_pool) (void)hipFree(s->d_pool);
@@ -817,6 +828,104 @@ int ff_render_to_pbo(FfState* s, const FfCamera* camera, const FfRenderParams* p
         st = fail(FF_ERR_HIP, "mapping the pixel buffer failed: %s", hipGetErrorString(e));
     }
     hipError_t ue = hipGraphicsUnmapResources(1, &s->pbo_resource, s->stream);       // :344
+    if (st == FF_OK && ue != hipSuccess) st = fail(FF_ERR_HIP, "hipGraphicsUnmapResources failed: %s", hipGetErrorString(ue));
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+// ---- progressive accumulation ("progressive accumulation across frames while the camera is still") ----
+
+namespace {
+
+// Frame `frame_index` of a progressive sequence into device buffers: an ordinary frame with seed + frame_index, added to
+// the running sum; outputs are the mean over frames 0..frame_index.
+int progressive_frame(FfState* s, const FfCamera* camera, const FfRenderParams* params, int frame_index, unsigned char* rgb8_dev, float* mean_dev)
+{
+    if (frame_index < 0) return fail(FF_ERR_INVALID_ARG, "ff_render_progressive: frame index %d", frame_index);
+    if (frame_index > 0 && (params->width != s->accum_width || params->height != s->accum_height || frame_index != s->accum_frames))
+        return fail(FF_ERR_INVALID_ARG, "ff_render_progressive: frame %d does not continue the running sequence (%d frames of %dx%d); restart with frame 0",
+                    frame_index, s->accum_frames, s->accum_width, s->accum_height);
+    const size_t values = (size_t)params->width * (size_t)params->height * 3;
+    int st = ensure_bytes((void**)&s->d_frame, &s->frame_bytes, values * sizeof(float) + 16);
+    if (st == FF_OK) st = ensure_bytes((void**)&s->d_accum, &s->accum_bytes, values * sizeof(float) + 16);
+    if (st != FF_OK) return st;
+    FfRenderParams p = *params;
+    p.seed = params->seed + (uint64_t)frame_index;
+    st = render_local(s, camera, &p, params->height, 0, 1, params->height, nullptr, s->d_frame);
+    if (st != FF_OK) return st;
+    const float inv = 1.0f / (float)(frame_index + 1);
+    FF_HIP(launch_accumulate(s->d_accum, s->d_frame, mean_dev, rgb8_dev, values, frame_index == 0 ? 1 : 0, inv, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    s->accum_width = params->width;
+    s->accum_height = params->height;
+    s->accum_frames = frame_index + 1;
+    return FF_OK;
+}
+
+} // namespace
+
+int ff_render_progressive(FfState* s, const FfCamera* camera, const FfRenderParams* params, int frame_index, void* rgb8, int rgb8_on_device, float* radiance,
+                          int radiance_on_device)
+{
+    clear_error();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_progressive: state is null");
+    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_progressive: camera is null");
+    int st = check_params(params);
+    if (st != FF_OK) return st;
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_progressive: no scene uploaded");
+    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
+        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
+    FF_HIP(hipSetDevice(s->device));
+    const size_t pixels = (size_t)params->width * (size_t)params->height;
+    unsigned char* rgb8_dev = nullptr;
+    float* mean_dev = nullptr;
+    if (rgb8) {
+        if (rgb8_on_device) rgb8_dev = (unsigned char*)rgb8;
+        else {
+            st = ensure_bytes((void**)&s->d_rgb8, &s->rgb8_bytes, pixels * 3 + 16);
+            if (st != FF_OK) return st;
+            rgb8_dev = s->d_rgb8;
+        }
+    }
+    if (radiance) {
+        if (radiance_on_device) mean_dev = radiance;
+        else {
+            st = ensure_bytes((void**)&s->d_mean, &s->mean_bytes, pixels * 3 * sizeof(float) + 16);
+            if (st != FF_OK) return st;
+            mean_dev = s->d_mean;
+        }
+    }
+    st = progressive_frame(s, camera, params, frame_index, rgb8_dev, mean_dev);
+    if (st != FF_OK) return st;
+    if (rgb8 && !rgb8_on_device) FF_HIP(hipMemcpy(rgb8, rgb8_dev, pixels * 3, hipMemcpyDeviceToHost));
+    if (radiance && !radiance_on_device) FF_HIP(hipMemcpy(radiance, mean_dev, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FF_OK;
+}
+
+int ff_render_to_pbo_progressive(FfState* s, const FfCamera* camera, const FfRenderParams* params, int frame_index)
+{
+    clear_error();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo_progressive: state is null");
+    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo_progressive: camera is null");
+    int st = check_params(params);
+    if (st != FF_OK) return st;
+    if (!s->pbo_resource) return fail(FF_ERR_GL_UNAVAILABLE, "ff_render_to_pbo_progressive: no pixel buffer registered");
+    if (params->width != s->pbo_width || params->height != s->pbo_height)
+        return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo_progressive: params are %dx%d but the registered buffer is %dx%d", params->width, params->height,
+                    s->pbo_width, s->pbo_height);
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_to_pbo_progressive: no scene uploaded");
+    FF_HIP(hipSetDevice(s->device));
+    void* dptr = nullptr;
+    size_t nbytes = 0;
+    FF_HIP(hipGraphicsMapResources(1, &s->pbo_resource, s->stream));
+    hipError_t e = hipGraphicsResourceGetMappedPointer(&dptr, &nbytes, s->pbo_resource);
+    if (e == hipSuccess && nbytes < (size_t)params->width * (size_t)params->height * 3) e = hipErrorInvalidValue;
+    if (e == hipSuccess) st = progressive_frame(s, camera, params, frame_index, (unsigned char*)dptr, nullptr);
+    else st = fail(FF_ERR_HIP, "mapping the pixel buffer failed: %s", hipGetErrorString(e));
+    hipError_t ue = hipGraphicsUnmapResources(1, &s->pbo_resource, s->stream);
     if (st == FF_OK && ue != hipSuccess) st = fail(FF_ERR_HIP, "hipGraphicsUnmapResources failed: %s", hipGetErrorString(ue));
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;

@@ -253,6 +253,23 @@ int ff_load_obj(const char* path, FfTriangle** out_triangles, int* out_count)
 
 void ff_free_triangles(FfTriangle* triangles) { std::free(triangles); }
 
+// saveToPPM (utilities.h:842-856) for the 8-bit framebuffer: same text format (P3, "W H", 255, one "r g b" line per
+// pixel, rows top to bottom as they sit in the buffer), to a caller-chosen path instead of ./render.ppm.
+int ff_save_ppm(const char* path, const unsigned char* rgb8, int width, int height)
+{
+    ff::clear_error();
+    if (!path || !rgb8 || width <= 0 || height <= 0) return ff::fail(FF_ERR_INVALID_ARG, "ff_save_ppm: bad argument");
+    std::FILE* f = std::fopen(path, "w");
+    if (!f) return ff::fail(FF_ERR_IO, "ff_save_ppm: cannot open %s for writing", path);
+    std::fprintf(f, "P3\n%d %d\n255\n", width, height);
+    const size_t n = (size_t)width * (size_t)height;
+    for (size_t i = 0; i < n; ++i) std::fprintf(f, "%d %d %d\n", (int)rgb8[3 * i], (int)rgb8[3 * i + 1], (int)rgb8[3 * i + 2]);
+    const bool ok = std::fflush(f) == 0 && !std::ferror(f);
+    std::fclose(f);
+    if (!ok) return ff::fail(FF_ERR_IO, "ff_save_ppm: write to %s failed", path);
+    return FF_OK;
+}
+
 } // extern "C"
 
 // -------------------------------------------------------------------------------------------------

@@ -81,6 +81,9 @@ size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads);
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream);
 // Sums every pixel's sample blocks in order, scales by 1/spp and writes radiance / rgb8 (row-major, coalesced).
 hipError_t launch_combine(const KParams& p, hipStream_t stream);
+// sum = first_frame ? frame : sum + frame; mean = sum * inv_frames (and its 8-bit quantisation); `values` floats.
+hipError_t launch_accumulate(float* sum, const float* frame, float* mean, unsigned char* rgb8, size_t values, int first_frame, float inv_frames,
+                             hipStream_t stream);
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream);
 hipError_t launch_deinterleave(const void* src, void* dst, int width, int height, int strip_rows, int num_parts, int elem_bytes,
                                hipStream_t stream);

@@ -590,18 +590,16 @@ __device__ __forceinline__ void inner_step(const Lds& L, const BvhNode* __restri
     const float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
     const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
     const int left = (int)q0.w, right = (int)q1.w;
-    if (hl && hr) {
-        const bool swap = rn < ln;
+    // Two short predicated regions instead of a four-way branch: the next node is a select; only the push (both hit) and
+    // the pop (none hit) touch LDS.
+    const bool both = hl && hr, swap = both && rn < ln;
+    const int next = (hl && !swap) ? left : right; // left if it is hit and not the farther of two hits, else right
+    if (both) {
         stack_push(L, S.sp, swap ? left : right);
         ++S.sp;
-        S.cur = swap ? right : left;
-    } else if (hl) {
-        S.cur = left;
-    } else if (hr) {
-        S.cur = right;
-    } else {
-        pop_subtree(L, S);
     }
+    if (hl || hr) S.cur = next;
+    else pop_subtree(L, S);
 }
 
 // One leaf visit: test the leaf's triangles (fast form), then take the next entry off the stack.  On a near tie with the
@@ -1475,6 +1473,19 @@ __global__ void combine_kernel(const KParams p)
     }
 }
 
+// Progressive accumulation (ff_render_progressive): running sum of whole frames, output = sum * (1 / frames).
+__global__ void accumulate_kernel(float* __restrict__ sum, const float* __restrict__ frame, float* __restrict__ mean, unsigned char* __restrict__ rgb8,
+                                  size_t values, int first_frame, float inv_frames)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= values) return;
+    const float acc = first_frame ? frame[i] : sum[i] + frame[i];
+    sum[i] = acc;
+    const float m = acc * inv_frames;
+    if (mean) mean[i] = m;
+    if (rgb8) rgb8[i] = to_u8(m);
+}
+
 // Strip de-interleave after the framebuffer gather: src = parts' compact row blocks back to back, dst = image order.
 __global__ void deinterleave_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int width, int height,
                                     int strip_rows, int num_parts, int elem_bytes)
@@ -1579,6 +1590,15 @@ hipError_t launch_combine(const KParams& p, hipStream_t stream)
     if (p.width <= 0 || p.local_rows <= 0) return hipSuccess;
     const dim3 block(256), grid((p.width + 255) / 256, p.local_rows);
     hipLaunchKernelGGL(combine_kernel, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(float* sum, const float* frame, float* mean, unsigned char* rgb8, size_t values, int first_frame, float inv_frames,
+                             hipStream_t stream)
+{
+    if (values == 0) return hipSuccess;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, stream, sum, frame, mean, rgb8, values, first_frame,
+                       inv_frames);
     return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@ EXPORTS = [
     "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh",
     "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
+    "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
     "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
 ]
@@ -76,6 +77,9 @@ def load():
     lib.ff_register_gl_pbo.argtypes = [vp, C.c_uint, i32, i32]
     lib.ff_unregister_gl_pbo.argtypes = [vp]
     lib.ff_render_to_pbo.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams)]
+    lib.ff_render_progressive.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, vp, i32, vp, i32]
+    lib.ff_render_to_pbo_progressive.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32]
+    lib.ff_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     lib.ff_set_collect_stats.argtypes = [vp, i32]
     lib.ff_stats.argtypes = [vp, P(T.FfStats)]
     lib.ff_debug_counters.argtypes = [vp, P(C.c_ulonglong)]
@@ -107,6 +111,12 @@ def load_obj(path):
         return T.triangles_to_array(ptr, n.value)
     finally:
         lib.ff_free_triangles(ptr)
+
+
+def save_ppm(path, rgb8):
+    """saveToPPM (utilities.h:842-856) for an [H, W, 3] uint8 frame."""
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    check(load().ff_save_ppm(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0]))
 
 
 class SceneFile:
@@ -243,6 +253,14 @@ class Tracer:
         check(self._lib.ff_render(self._state, C.byref(camera), C.byref(params),
                                   rgb8.ctypes.data if want_rgb8 else None, 0,
                                   rad.ctypes.data if want_radiance else None, 0))
+        return rgb8, rad
+
+    def render_progressive(self, camera, params, frame_index):
+        """Frame `frame_index` of a progressive sequence -> (rgb8, radiance) of the mean over frames 0..frame_index."""
+        h, w = params.height, params.width
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        rad = np.zeros((h, w, 3), dtype=np.float32)
+        check(self._lib.ff_render_progressive(self._state, C.byref(camera), C.byref(params), frame_index, rgb8.ctypes.data, 0, rad.ctypes.data, 0))
         return rgb8, rad
 
     def render_device(self, camera, params, rgb8_ptr=None, radiance_ptr=None):

@@ -166,6 +166,21 @@ FF_API int ff_unregister_gl_pbo(FfState* state);
 /* map -> clear -> trace -> unmap  (kernel.cu:337-344).  params->width/height must match the registration. */
 FF_API int ff_render_to_pbo(FfState* state, const FfCamera* camera, const FfRenderParams* params);
 
+/* ---- progressive accumulation (the reference's README sketches it) ------------------- */
+
+/* Frame `frame_index` (0, 1, 2, ... while the camera is still) of a progressive sequence: an ordinary frame rendered with
+ * seed + frame_index, added in fp32 to a running per-pixel sum kept in the state; the outputs are sum * (1 / frames) and
+ * its 8-bit quantisation.  frame_index 0 restarts the sequence (call it when the camera or the scene changed); other
+ * indices must continue it.  Buffers as in ff_render. */
+FF_API int ff_render_progressive(FfState* state, const FfCamera* camera, const FfRenderParams* params, int frame_index, void* rgb8, int rgb8_on_device,
+                                 float* radiance, int radiance_on_device);
+
+/* The same into the registered pixel buffer (the per-frame block of kernel.cu:335-344). */
+FF_API int ff_render_to_pbo_progressive(FfState* state, const FfCamera* camera, const FfRenderParams* params, int frame_index);
+
+/* saveToPPM (utilities.h:842-856) for the 8-bit framebuffer: P3 text, one "r g b" line per pixel, top row first. */
+FF_API int ff_save_ppm(const char* path, const unsigned char* rgb8, int width, int height);
+
 /* ---- measurement -------------------------------------------------------------------------------- */
 
 /* Turn per-launch node/triangle visit counters on (1) or off (0, default).  Ray counting is always on. */

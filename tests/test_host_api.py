@@ -165,3 +165,19 @@ def test_strip_rows_helper(ff):
         assert sum(rows) == h
     assert lib.ff_strips_local_rows(1080, 16, 0, 8) == 9 * 16 and lib.ff_strips_local_rows(1080, 16, 3, 8) == 8 * 16 + 8
     assert lib.ff_strips_local_rows(0, 16, 0, 1) == 0 and lib.ff_strips_local_rows(10, 0, 0, 1) == 0
+
+
+def test_save_ppm_matches_reference_format(ff, tmp_path):
+    """saveToPPM (utilities.h:842-856): "P3", "W H", "255", then one "r g b" line per pixel in buffer order."""
+    import numpy as np
+    from gpupathtracer_amd import lib as L
+    img = np.arange(4 * 3 * 3, dtype=np.uint8).reshape(3, 4, 3) * 7
+    path = tmp_path / "render.ppm"
+    L.save_ppm(str(path), img)
+    lines = path.read_text().split("\n")
+    assert lines[:3] == ["P3", "4 3", "255"]
+    body = [tuple(int(v) for v in ln.split()) for ln in lines[3:] if ln]
+    assert body == [tuple(int(v) for v in px) for px in img.reshape(-1, 3)]
+    with pytest.raises(L.FireflyError) as e:
+        L.save_ppm(str(tmp_path / "no_such_dir" / "x.ppm"), img)
+    assert e.value.status == 7  # FF_ERR_IO
