@@ -996,7 +996,9 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
             Ly = 0.f + P.by * emission.y;
             Lz = 0.f + P.bz * emission.z;
         } else {
-            // everything else is diffuse (utilities.h:109); cosine-weighted sampling, so f*cos/pdf = albedo
+            // MIRROR: perfect reflection, throughput *= m_specularColor (the record's tint slot holds it); everything else is
+            // diffuse (utilities.h:109): cosine-weighted sampling, so f*cos/pdf = albedo
+            const bool mirror = mat_bxdf(M) == FF_BXDF_MIRROR;
             const float4 albedo = mat_f4(M, 12);
             P.bx = P.bx * albedo.x;
             P.by = P.by * albedo.y;
@@ -1005,21 +1007,29 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                 const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
                 float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
                 if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; }
-                unsigned r0, r1;
-                const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
-                philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
-                const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
-                float wlx, wly, wlz;
-                cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
-                // orthonormal basis (Duff et al. 2017)
-                const float sign = copysignf(1.0f, uz);
-                const float aa = -1.0f / (sign + uz);
-                const float bb = (ux * uy) * aa;
-                const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
-                const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
-                const float wox = (t0 * wlx + s0 * wly) + ux * wlz;
-                const float woy = (t1 * wlx + s1 * wly) + uy * wlz;
-                const float woz = (t2 * wlx + s2 * wly) + uz * wlz;
+                float wox, woy, woz;
+                if (mirror) {
+                    const float k2 = 2.0f * dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz);
+                    wox = P.ray.dx - k2 * ux;
+                    woy = P.ray.dy - k2 * uy;
+                    woz = P.ray.dz - k2 * uz;
+                } else {
+                    unsigned r0, r1;
+                    const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
+                    philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
+                    const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
+                    float wlx, wly, wlz;
+                    cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
+                    // orthonormal basis (Duff et al. 2017)
+                    const float sign = copysignf(1.0f, uz);
+                    const float aa = -1.0f / (sign + uz);
+                    const float bb = (ux * uy) * aa;
+                    const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
+                    const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
+                    wox = (t0 * wlx + s0 * wly) + ux * wlz;
+                    woy = (t1 * wlx + s1 * wly) + uy * wlz;
+                    woz = (t2 * wlx + s2 * wly) + uz * wlz;
+                }
                 P.ray.ox = best.px + ux * kRayEps;
                 P.ray.oy = best.py + uy * kRayEps;
                 P.ray.oz = best.pz + uz * kRayEps;

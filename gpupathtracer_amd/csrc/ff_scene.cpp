@@ -355,7 +355,9 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
         r.nrm_c0[3] = nrm.c[3].x * 0.0f; r.nrm_c1[3] = nrm.c[3].y * 0.0f; r.nrm_c2[3] = nrm.c[3].z * 0.0f;
         r.plane_n[0] = g.m_normal.x; r.plane_n[1] = g.m_normal.y; r.plane_n[2] = g.m_normal.z;
         const FfBXDF& b = *g.m_bxdf;
-        r.albedo[0] = b.m_albedo.x; r.albedo[1] = b.m_albedo.y; r.albedo[2] = b.m_albedo.z;
+        // throughput factor of a bounce off this surface: m_specularColor for MIRROR, m_albedo otherwise
+        const FfVec3& tint = b.m_type == FF_BXDF_MIRROR ? b.m_specularColor : b.m_albedo;
+        r.albedo[0] = tint.x; r.albedo[1] = tint.y; r.albedo[2] = tint.z;
         r.emission[0] = b.m_emissiveColor.x * b.m_intensity; // utilities.h:102
         r.emission[1] = b.m_emissiveColor.y * b.m_intensity;
         r.emission[2] = b.m_emissiveColor.z * b.m_intensity;

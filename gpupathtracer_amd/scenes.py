@@ -55,9 +55,10 @@ def subdivide_sphere(tris, levels):
     return out
 
 
-def make_bxdf(kind, albedo=(-1, -1, -1), emissive=(-1, -1, -1), intensity=-1.0):
+def make_bxdf(kind, albedo=(-1, -1, -1), emissive=(-1, -1, -1), intensity=-1.0, specular=(-1, -1, -1)):
     b = T.FfBXDF()
     L.load().ff_bxdf_init(C.byref(b))  # utilities.h:81-88 defaults
+    b.m_specularColor = T.FfVec3(*specular)
     b.m_type = kind
     b.m_albedo = T.FfVec3(*albedo)
     b.m_emissiveColor = T.FfVec3(*emissive)
@@ -157,6 +158,19 @@ def cornell_wahoo_scene(wahoo=None, cube=None):
     s.add_mesh(wahoo, (0, -2.4, 0), (0, 0, 0), (0.28, 0.28, 0.28), make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0)))  # kernel.cu:239 albedo
     s.add_mesh(cube, (1.5, -2.0, 1.0), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.75, 0.75, 0.75)))
     return _box(s).finalize()
+
+
+def cornell_mirror_scene(sphere=None, cube=None):
+    """The C2 box with a MIRROR back wall and a MIRROR cube next to a diffuse sphere (BXDFTyp::MIRROR, utilities.h:68-75)."""
+    sphere = load_mesh("sphereBlender") if sphere is None else sphere
+    cube = load_mesh("cube") if cube is None else cube
+    s = Scene()
+    s.add_mesh(sphere, (-0.9, -1.5, -0.3), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.2, 0.4, 0.9)))
+    s.add_mesh(cube, (1.2, -1.9, 0.4), (0, 30, 0), (1.2, 1.2, 1.2), make_bxdf(T.BXDF_MIRROR, specular=(0.95, 0.9, 0.8)))
+    _box(s)
+    kind, pos, rot, scl, tris, _ = s._specs[2]  # the back wall becomes a mirror
+    s._specs[2] = (kind, pos, rot, scl, tris, make_bxdf(T.BXDF_MIRROR, specular=(0.9, 0.9, 0.9)))
+    return s.finalize()
 
 
 def blooper_scene(rocketman=None, cube=None):

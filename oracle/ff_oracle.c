@@ -649,10 +649,14 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
                 L[2] = L[2] + beta[2] * Le[2];
                 break;
             }
-            /* everything else is diffuse (U:109 is a constant-true test) */
-            beta[0] = beta[0] * bx->m_albedo.x;
-            beta[1] = beta[1] * bx->m_albedo.y;
-            beta[2] = beta[2] * bx->m_albedo.z;
+            /* MIRROR (U:68-75 declares it, U:108 leaves it as a TODO; build-defined): perfect specular reflection about the
+             * shading normal, throughput *= m_specularColor, no random numbers consumed.
+             * Everything else (DIFFUSE, and GLASS, which falls through like U:109's constant-true test) is diffuse. */
+            const int mirror = bx->m_type == FF_BXDF_MIRROR;
+            const FfVec3 tint = mirror ? bx->m_specularColor : bx->m_albedo;
+            beta[0] = beta[0] * tint.x;
+            beta[1] = beta[1] * tint.y;
+            beta[2] = beta[2] * tint.z;
             if (b == p->bounces - 1) break;
             /* Shading normal: the direction of inverse(transpose(M)) * n_obj, normalised once.  For triangles the
              * un-normalised face normal cross(e1, e2) is transformed (the reference's Intersect carries its normalised
@@ -675,16 +679,25 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
             }
             orc_normalize3(nw4, nrm);
             if (orc_dot3(nrm, &ray.m_direction.x) > 0.f) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
-            float u1, u2, wl[3], tt[3], bb[3];
-            uint32_t k24;
-            orc_sample_uniforms(pixel_index, (uint32_t)s, (uint32_t)b, p->seed, &u1, &u2, &k24);
-            (void)u2;
-            orc_cosine_sample_hemisphere(u1, k24, wl);
-            orc_onb(nrm, tt, bb);
-            /* the local direction is unit and the basis orthonormal: the world direction is used as is (|wo| = 1 +- 1e-6) */
-            float wo[3] = { (tt[0] * wl[0] + bb[0] * wl[1]) + nrm[0] * wl[2],
-                            (tt[1] * wl[0] + bb[1] * wl[1]) + nrm[1] * wl[2],
-                            (tt[2] * wl[0] + bb[2] * wl[1]) + nrm[2] * wl[2] };
+            float wo[3];
+            if (mirror) {
+                /* wo = d - (2 (n.d)) n with the facing normal: the reflected direction keeps the length of d */
+                const float k2 = 2.0f * orc_dot3(nrm, &ray.m_direction.x);
+                wo[0] = ray.m_direction.x - k2 * nrm[0];
+                wo[1] = ray.m_direction.y - k2 * nrm[1];
+                wo[2] = ray.m_direction.z - k2 * nrm[2];
+            } else {
+                float u1, u2, wl[3], tt[3], bb[3];
+                uint32_t k24;
+                orc_sample_uniforms(pixel_index, (uint32_t)s, (uint32_t)b, p->seed, &u1, &u2, &k24);
+                (void)u2;
+                orc_cosine_sample_hemisphere(u1, k24, wl);
+                orc_onb(nrm, tt, bb);
+                /* the local direction is unit and the basis orthonormal: the world direction is used as is (|wo| = 1 +- 1e-6) */
+                wo[0] = (tt[0] * wl[0] + bb[0] * wl[1]) + nrm[0] * wl[2];
+                wo[1] = (tt[1] * wl[0] + bb[1] * wl[1]) + nrm[1] * wl[2];
+                wo[2] = (tt[2] * wl[0] + bb[2] * wl[1]) + nrm[2] * wl[2];
+            }
             ray.m_origin.x = is.m_intersectionPoint.x + nrm[0] * ORC_RAY_EPS;
             ray.m_origin.y = is.m_intersectionPoint.y + nrm[1] * ORC_RAY_EPS;
             ray.m_origin.z = is.m_intersectionPoint.z + nrm[2] * ORC_RAY_EPS;

@@ -37,6 +37,8 @@ CASES = {
     "path_cornell_64x48_b8_s2_seed7": (scenes.cornell_wahoo_scene, "inside", lambda: _path(64, 48, 8, 2, seed=7)),
     "path_blooper_64x64_b3_s3": (scenes.blooper_scene, "oblique", lambda: _path(64, 64, 3, 3)),
     "path_cornell_40x30_b1_s1": (scenes.cornell_wahoo_scene, "default", lambda: _path(40, 30, 1, 1)),
+    # BXDFTyp::MIRROR (build-defined): mirror back wall + mirror cube, long specular chains
+    "path_mirror_80x60_b6_s3": (scenes.cornell_mirror_scene, "inside", lambda: _path(80, 60, 6, 3, seed=77)),
 }
 
 
