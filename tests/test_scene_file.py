@@ -72,3 +72,14 @@ def test_scene_file_missing():
     with pytest.raises(lib.FireflyError) as e:
         lib.SceneFile("/nonexistent/x.scene")
     assert e.value.status == T.FF_ERR_IO
+
+
+def test_scene_file_mirror_bxdf(tmp_path):
+    p = tmp_path / "mirror.scene"
+    p.write_text("bxdf m mirror specular 0.9 0.8 0.7\nbxdf l emitter color 1 1 1 intensity 3\n"
+                 "plane position 0 0 -2 scale 4 4 4 bxdf m\nplane position 0 2 0 rotation 90 0 0 bxdf l\n")
+    sf = lib.SceneFile(str(p))
+    b = sf.geometries[0].m_bxdf.contents
+    assert b.m_type == T.BXDF_MIRROR
+    assert (b.m_specularColor.x, b.m_specularColor.y, b.m_specularColor.z) == pytest.approx((0.9, 0.8, 0.7))
+    sf.close()
