@@ -1175,6 +1175,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         atomicAdd(&p.counters[6], tphase[2]);
         atomicAdd(&p.counters[7], tphase[3]);
         atomicAdd(&p.counters[13], tphase[4]);
+        atomicMax(&p.counters[22], tphase[0] + tphase[1] + tphase[2] + tphase[3] + tphase[4]); // slowest wave
     }
     flush_counters(p, lane, cnt, STATS);
 }

@@ -1,13 +1,23 @@
 #!/usr/bin/env python3
-"""Print the SIMD occupancy of each phase of the BVH kernel on the C2 workload (instrumented launch)."""
+"""Print the SIMD occupancy of each phase of the BVH kernel (instrumented launch).
+Usage: occupancy_probe.py [spp] [c2|c3|c4] [sah|lbvh]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpupathtracer_amd import lib, scenes, types as T
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-scene = scenes.cornell_wahoo_scene()
+which = sys.argv[2] if len(sys.argv) > 2 else "c2"
+builder = T.BUILD_GPU_LBVH if len(sys.argv) > 3 and sys.argv[3] == "lbvh" else T.BUILD_HOST_SAH
 cam = scenes.posed_camera(1920, 1080, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+if which == "c3":
+    scene = scenes.blooper_scene()
+    cam = scenes.posed_camera(1920, 1080, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0)
+elif which == "c4":
+    scene = scenes.sphere_stress_scene(5)
+else:
+    scene = scenes.cornell_wahoo_scene()
 with lib.Tracer(0) as t:
+    t.set_builder(builder)
     t.upload_scene(scene)
     t.set_collect_stats(True)
     t.render(cam, lib.render_params(1920, 1080, 8, spp), want_rgb8=False, want_radiance=False)
@@ -34,3 +44,5 @@ if tt:
 tb = c[19] + c[20] + c[21]
 if tb:
     print(f"begin split: quad boxes {c[19] / tb:.3f}  quad screens {c[20] / tb:.3f}  mesh boxes {c[21] / tb:.3f}   cycles per segment round {tb / max(sr, 1):.0f}")
+loop = c[4] + c[5] + c[6] + c[7] + c[13]
+print(f"stamped loop time per wave: mean {loop / 4096 / 1e6:.2f} M ticks, slowest wave {c[22] / 1e6:.2f} M; kernel {st.kernel_ms:.2f} ms = {st.kernel_ms * 2.4:.2f} M cycles at 2.4 GHz")
