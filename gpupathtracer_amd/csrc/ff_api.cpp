@@ -438,7 +438,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     s->h_geoms = cs.geoms;
     s->num_geoms = (int)cs.geoms.size();
     s->num_planes = 0;
-    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type == FF_GEOM_PLANE ? 1 : 0;
+    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records
     s->num_tris = cs.total_tris;
     s->scene_builder = FF_BUILD_GPU_LBVH;
     refresh_scene_extent(s);
@@ -491,7 +491,7 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     s->build_stats.copy_ms = ms_since(t_copy);
     s->num_geoms = (int)cs.geoms.size();
     s->num_planes = 0;
-    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type == FF_GEOM_PLANE ? 1 : 0;
+    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records
     s->num_tris = cs.tris.size();
     s->node_capacity = cs.nodes.size();
     // Each mesh's nodes are contiguous with the root first: slot = [root, next mesh's root).

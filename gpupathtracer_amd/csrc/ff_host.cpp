@@ -377,8 +377,9 @@ int ff_scene_file_load(const char* path, FfSceneFile** out_scene)
                 else if (key == "intensity") { if (!read_floats(tok, i, 1, v)) bad("intensity needs a number"); else b->m_intensity = v[0]; }
                 else bad("unknown bxdf key");
             }
-        } else if (tok[0] == "mesh" || tok[0] == "plane") {
-            const bool is_mesh = tok[0] == "mesh";
+        } else if (tok[0] == "mesh" || tok[0] == "plane" || tok[0] == "sphere") {
+            const bool is_mesh = tok[0] == "mesh", is_sphere = tok[0] == "sphere";
+            float radius = 0.f;
             FfTriangle* tris = nullptr;
             int ntris = 0;
             if (is_mesh) {
@@ -388,6 +389,8 @@ int ff_scene_file_load(const char* path, FfSceneFile** out_scene)
                 if (st != FF_OK) { status = st; break; }
                 sc->meshes.push_back(tris);
                 i = 2;
+            } else {
+                i = 1;
             }
             FfVec3 pos{ 0, 0, 0 }, rot{ 0, 0, 0 }, scl{ 1, 1, 1 };
             FfBXDF* bx = nullptr;
@@ -397,6 +400,7 @@ int ff_scene_file_load(const char* path, FfSceneFile** out_scene)
                 if (key == "position") { if (!read_floats(tok, i, 3, v)) bad("position needs 3 numbers"); else pos = FfVec3{ v[0], v[1], v[2] }; }
                 else if (key == "rotation") { if (!read_floats(tok, i, 3, v)) bad("rotation needs 3 numbers"); else rot = FfVec3{ v[0], v[1], v[2] }; }
                 else if (key == "scale") { if (!read_floats(tok, i, 3, v)) bad("scale needs 3 numbers"); else scl = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "radius" && is_sphere) { if (!read_floats(tok, i, 1, v) || !(v[0] > 0.f)) bad("radius needs a positive number"); else radius = v[0]; }
                 else if (key == "bxdf") {
                     if (i >= tok.size()) { bad("bxdf needs a name"); break; }
                     for (auto& b : sc->bxdfs) if (b.first == tok[i]) bx = b.second;
@@ -406,8 +410,9 @@ int ff_scene_file_load(const char* path, FfSceneFile** out_scene)
             }
             if (status != FF_OK) break;
             if (!bx) { bad("geometry needs a bxdf"); break; }
+            if (is_sphere && !(radius > 0.f)) { bad("sphere needs a radius"); break; }
             FfGeometry g;
-            ff_geometry_init(&g, is_mesh ? FF_GEOM_TRIANGLEMESH : FF_GEOM_PLANE, pos, rot, scl, tris, ntris, 0.f);
+            ff_geometry_init(&g, is_mesh ? FF_GEOM_TRIANGLEMESH : (is_sphere ? FF_GEOM_SPHERE : FF_GEOM_PLANE), pos, rot, scl, tris, ntris, radius);
             g.m_bxdf = bx;
             sc->geometries.push_back(g);
         } else {

@@ -146,6 +146,7 @@ __device__ __forceinline__ void fill_object_normal(const GeomRecord* __restrict_
     }
 }
 
+
 // kernel.cu:35-108 (Möller-Trumbore, division deferred, back faces culled).  Returns the object-space t or -1.
 // A = (v0, original index), E1 = (v1 - v0, cull margin), E2 = (v2 - v0, -): the edges of :44-45 come with the record.
 __device__ __forceinline__ float triangle_t(const float4 A, const float4 E1, const float4 E2, const Ray& r)
@@ -178,6 +179,44 @@ __device__ __forceinline__ float plane_t(float nx, float ny, float nz, const Ray
     const float Px = r.ox + t * r.dx, Py = r.oy + t * r.dy;        // :16
     if (!(Px >= -0.5f && Px <= 0.5f && Py >= -0.5f && Py <= 0.5f)) return -1.0f; // :18
     return t > 0.0f ? t : -1.0f;                                   // :23
+}
+
+// Sphere of radius `rad` about the object-space origin (build-defined: the reference only printf's at kernel.cu:166-169;
+// oracle/ff_oracle.c orc_intersect_sphere is the definition).  Two-sided, nearest root above EPSILON.  Returns t or -1.
+__device__ __forceinline__ float sphere_t(float rad, const Ray& r)
+{
+    const float b = dot3(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+    const float c = dot3(r.ox, r.oy, r.oz, r.ox, r.oy, r.oz) - rad * rad;
+    const float disc = b * b - c;
+    if (!(disc >= 0.0f)) return -1.0f;
+    const float sq = sqrtf(disc);
+    float t = -b - sq;
+    if (!(t > kTriEpsilon)) {
+        t = -b + sq;
+        if (!(t > kTriEpsilon)) return -1.0f;
+    }
+    return t;
+}
+
+// Unit object-space normal of a sphere hit at parameter t: P * (1 / rad).
+__device__ __forceinline__ void sphere_normal(float rad, const Ray& r, float t, float& nx, float& ny, float& nz)
+{
+    const float inv = 1.0f / rad;
+    nx = (r.ox + r.dx * t) * inv;
+    ny = (r.oy + r.dy * t) * inv;
+    nz = (r.oz + r.dz * t) * inv;
+}
+
+// The same for a sphere: the winning hit is evaluated once more (same arithmetic, same result) for its object-space point.
+__device__ __forceinline__ void fill_sphere_normal(const GeomRecord* __restrict__ geoms, const Ray& wr, Best& best)
+{
+    if (best.geom < 0 || geoms[best.geom].type != FF_GEOM_SPHERE) return;
+    const GeomRecord& G = geoms[best.geom];
+    Ray osr;
+    float len;
+    object_space_ray(G, wr, osr, len);
+    const float t = sphere_t(G.plane_n[3], osr);
+    sphere_normal(G.plane_n[3], osr, t, best.cx, best.cy, best.cz);
 }
 
 // ---- LDS layout of the BVH kernels -----------------------------------------------------------------------------------
@@ -377,10 +416,15 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
         H.cz = e1x * e2y - e2x * e1y;
     } else {
         const float4 pn = lds_geom4(L, g, 11);
-        t = plane_t(pn.x, pn.y, pn.z, osr);
-        H.cx = pn.x; // kernel.cu:26
-        H.cy = pn.y;
-        H.cz = pn.z;
+        if (lds_geom_i4(L, g, 16).x == FF_GEOM_SPHERE) {
+            t = sphere_t(pn.w, osr);
+            sphere_normal(pn.w, osr, t, H.cx, H.cy, H.cz);
+        } else {
+            t = plane_t(pn.x, pn.y, pn.z, osr);
+            H.cx = pn.x; // kernel.cu:26
+            H.cy = pn.y;
+            H.cz = pn.z;
+        }
     }
     if (!(t > 0.0f)) return false;
     const float4 m0 = lds_geom4(L, g, 4), m1 = lds_geom4(L, g, 5), m2 = lds_geom4(L, g, 6), m3 = lds_geom4(L, g, 7);
@@ -473,6 +517,20 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
         const int g = __ffs((int)quads) - 1;
         quads &= quads - 1u;
         if (STATS) { cnt.planes += 1; probe_round(cnt.plane_rounds); }
+        if (lds_geom_i4(L, g, 16).x == FF_GEOM_SPHERE) {
+            // spheres have no screening form: the exact test runs here and yields the approximate world distance
+            Ray osr;
+            float len;
+            object_space_ray_lds(L, g, wr, osr, len);
+            const float tt = sphere_t(lds_geom4(L, g, 11).w, osr);
+            const float sdist = tt * wlen * __builtin_amdgcn_rcpf(len);
+            if (tt > 0.0f && offer(sdist, g, -1, S.pend, S.best)) {
+                HitPoint H;
+                resolve_pending(L, tris, wr, S.pend, S.best, H);
+                offer(sdist, g, -1, S.pend, S.best);
+            }
+            continue;
+        }
         const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
         const float4 pn = lds_geom4(L, g, 11);
         // object-space origin and un-normalised direction (screening only: FMA form)
@@ -769,12 +827,13 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
             }
         } else if (live) {
             if (STATS) cnt.planes += 1;
-            const float t = plane_t(G.plane_n[0], G.plane_n[1], G.plane_n[2], osr);
+            const float t = G.type == FF_GEOM_SPHERE ? sphere_t(G.plane_n[3], osr) : plane_t(G.plane_n[0], G.plane_n[1], G.plane_n[2], osr);
             if (t > 0.0f) consider(G, g, -1, -1, t, osr, wr, geoms, tris, best);
         }
     }
     if (live) {
         fill_object_normal(geoms, tris, best);
+        fill_sphere_normal(geoms, wr, best);
         cnt.rays += 1;
     }
 }

@@ -335,9 +335,10 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
         const FfGeometry& g = geoms[i];
         GeomRecord& r = out.geoms[i];
         std::memset(&r, 0, sizeof r);
-        if (g.m_geometryType != FF_GEOM_PLANE && g.m_geometryType != FF_GEOM_TRIANGLEMESH)
-            return fail(FF_ERR_UNSUPPORTED, "geometry %d: type %d is not implemented (the reference only prints, kernel.cu:166-173)", i,
-                        g.m_geometryType);
+        if (g.m_geometryType != FF_GEOM_PLANE && g.m_geometryType != FF_GEOM_TRIANGLEMESH && g.m_geometryType != FF_GEOM_SPHERE)
+            return fail(FF_ERR_UNSUPPORTED, "geometry %d: type %d is not a geometry type (kernel.cu:170-173)", i, g.m_geometryType);
+        if (g.m_geometryType == FF_GEOM_SPHERE && !(g.m_sphereRadius > 0.f))
+            return fail(FF_ERR_INVALID_ARG, "geometry %d: sphere radius %g", i, (double)g.m_sphereRadius);
         if (!g.m_bxdf) return fail(FF_ERR_INVALID_ARG, "geometry %d: m_bxdf is null (the reference copies it unconditionally, kernel.cu:282)", i);
         const M4 inv = load(g.m_inverseModelMatrix.m), mod = load(g.m_modelMatrix.m);
         // The kernel drops the w row of the object-space transform (kernel.cu:138 normalises a vec4 whose w is 0 for
@@ -354,6 +355,7 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
         r.inv_c0[3] = inv.c[3].x * 0.0f; r.inv_c1[3] = inv.c[3].y * 0.0f; r.inv_c2[3] = inv.c[3].z * 0.0f;
         r.nrm_c0[3] = nrm.c[3].x * 0.0f; r.nrm_c1[3] = nrm.c[3].y * 0.0f; r.nrm_c2[3] = nrm.c[3].z * 0.0f;
         r.plane_n[0] = g.m_normal.x; r.plane_n[1] = g.m_normal.y; r.plane_n[2] = g.m_normal.z;
+        r.plane_n[3] = g.m_geometryType == FF_GEOM_SPHERE ? g.m_sphereRadius : 0.f; // w slot: sphere radius
         const FfBXDF& b = *g.m_bxdf;
         // throughput factor of a bounce off this surface: m_specularColor for MIRROR, m_albedo otherwise
         const FfVec3& tint = b.m_type == FF_BXDF_MIRROR ? b.m_specularColor : b.m_albedo;
@@ -367,6 +369,8 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
         r.orig_index = i;
         // object-space bounds -> world AABB (pruning only, padded below)
         float omn[3] = { -0.5f, -0.5f, 0.f }, omx[3] = { 0.5f, 0.5f, 0.f }; // unit plane quad, kernel.cu:18
+        if (g.m_geometryType == FF_GEOM_SPHERE)
+            for (int k = 0; k < 3; ++k) { omn[k] = -g.m_sphereRadius; omx[k] = g.m_sphereRadius; }
         if (g.m_geometryType == FF_GEOM_TRIANGLEMESH) {
             Box ob;
             ob.reset();
@@ -395,11 +399,11 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
             out.total_tris += (uint64_t)cnt;
         }
     }
-    // Processing order: planes first (cheap, they tighten the distance bound), then meshes by ascending triangle count (a
+    // Processing order: analytic shapes (planes, spheres) first (cheap, they tighten the distance bound), then meshes by ascending triangle count (a
     // lane walks its candidate meshes one after the other; short traversals first keeps the wave's lanes in step for longer).
     // The closest hit does not depend on this order: ties are broken on orig_index exactly like the reference's loop.
     std::stable_sort(out.geoms.begin(), out.geoms.end(), [](const GeomRecord& a, const GeomRecord& b) {
-        const bool pa = a.type == FF_GEOM_PLANE, pb = b.type == FF_GEOM_PLANE;
+        const bool pa = a.type != FF_GEOM_TRIANGLEMESH, pb = b.type != FF_GEOM_TRIANGLEMESH;
         if (pa != pb) return pa;
         if (pa) return false;
         return a.tri_count < b.tri_count;

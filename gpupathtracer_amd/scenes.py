@@ -82,18 +82,25 @@ class Scene:
         self._specs.append((T.GEOM_PLANE, position, rotation, scale, None, bxdf))
         return self
 
+    def add_sphere(self, radius, position=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1), bxdf=None):
+        """SPHERE geometry (utilities.h:193-195): object-space radius, placed by the same T*R*S transform."""
+        self._specs.append((T.GEOM_SPHERE, position, rotation, scale, float(radius), bxdf))
+        return self
+
     def finalize(self):
         lib = L.load()
         n = len(self._specs)
         self.geometries = (T.FfGeometry * n)()
         self._keep = []
         for i, (kind, pos, rot, scl, tris, bxdf) in enumerate(self._specs):
-            tbuf, cnt = None, 0
-            if tris is not None and len(tris):
+            tbuf, cnt, radius = None, 0, 0.0
+            if kind == T.GEOM_SPHERE:
+                radius = tris  # the spec's payload slot carries the radius
+            elif tris is not None and len(tris):
                 tbuf = T.triangles_from_array(tris)
                 cnt = len(tbuf)
             lib.ff_geometry_init(C.byref(self.geometries[i]), kind, T.FfVec3(*pos), T.FfVec3(*rot), T.FfVec3(*scl),
-                                 tbuf, cnt, 0.0)
+                                 tbuf, cnt, radius)
             if bxdf is not None:
                 self.geometries[i].m_bxdf = C.pointer(bxdf)
             self._keep.append((tbuf, bxdf))
@@ -104,7 +111,7 @@ class Scene:
 
     @property
     def triangle_count(self):
-        return int(sum(len(s[4]) for s in self._specs if s[4] is not None))
+        return int(sum(len(s[4]) for s in self._specs if s[0] == T.GEOM_TRIANGLEMESH and s[4] is not None))
 
 
 def default_camera(width, height):
@@ -170,6 +177,19 @@ def cornell_mirror_scene(sphere=None, cube=None):
     _box(s)
     kind, pos, rot, scl, tris, _ = s._specs[2]  # the back wall becomes a mirror
     s._specs[2] = (kind, pos, rot, scl, tris, make_bxdf(T.BXDF_MIRROR, specular=(0.9, 0.9, 0.9)))
+    return s.finalize()
+
+
+def cornell_spheres_scene(cube=None):
+    """The C2 box with SPHERE geometries (utilities.h:193-195): a diffuse one, a squashed and rotated diffuse one, a mirror
+    one, and the cube mesh between them."""
+    cube = load_mesh("cube") if cube is None else cube
+    s = Scene()
+    s.add_mesh(cube, (0.1, -2.0, -0.6), (0, 20, 0), (1, 1, 1), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.75, 0.75, 0.75)))
+    _box(s)
+    s.add_sphere(0.8, (-1.3, -1.7, 0.3), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.2, 0.5, 0.9)))
+    s.add_sphere(0.5, (1.4, -1.9, 0.8), (20, 0, 35), (1.6, 1.0, 1.2), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.9, 0.6, 0.1)))
+    s.add_sphere(0.6, (0.9, 0.4, -1.2), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_MIRROR, specular=(0.95, 0.95, 0.95)))
     return s.finalize()
 
 

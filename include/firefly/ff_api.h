@@ -38,7 +38,7 @@ typedef enum FfStatus {
     FF_ERR_NO_DEVICE      = 2,  /* no HIP device / HIP runtime failure at create */
     FF_ERR_HIP            = 3,  /* a HIP call failed; see ff_last_error() */
     FF_ERR_NO_SCENE       = 4,  /* render called before ff_upload_scene */
-    FF_ERR_UNSUPPORTED    = 5,  /* e.g. SPHERE geometry (kernel.cu:166-169 only printf's) */
+    FF_ERR_UNSUPPORTED    = 5,  /* e.g. a non-affine model matrix, an unknown geometry type (kernel.cu:170-173) */
     FF_ERR_GL_UNAVAILABLE = 6,  /* HIP-GL interop not usable (headless box) */
     FF_ERR_IO             = 7,  /* file could not be read / parsed */
     FF_ERR_OOM            = 8
@@ -90,7 +90,8 @@ FF_API void ff_camera_ray_matrix(const FfCamera* c, FfMat4* out_inv_view_times_i
  * 48-byte triangle records, per-geometry transform records and one object-space BVH per mesh.
  * The host arrays are only read and may be freed after the call.  A second call replaces the scene
  * and frees the previous one (the reference leaks it, kernel.cu:364-368).
- * SPHERE geometries are rejected with FF_ERR_UNSUPPORTED. */
+ * SPHERE geometries (declared by the reference, utilities.h:193-195, but only printf'ed by its kernel, kernel.cu:166-169)
+ * are intersected analytically in object space: radius m_sphereRadius about the origin, two-sided. */
 FF_API int ff_upload_scene(FfState* state, const FfGeometry* host_geometries, int n);
 
 /* ---- dynamic scenes (no counterpart in the reference, whose upload is one-off) ------- */
@@ -211,6 +212,7 @@ FF_API void ff_free_triangles(FfTriangle* triangles);
  *   bxdf NAME diffuse|emitter|mirror|glass [albedo R G B] [specular R G B] [color R G B] [intensity I]
  *   mesh FILE.obj [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME (path relative to the scene file)
  *   plane [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME
+ *   sphere radius R [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME
  *
  * Geometries keep file order (it is the reference's iteration order, kernel.cu:133).  The returned object owns the
  * triangles and BXDFs its FfGeometry array points to. */

@@ -420,6 +420,36 @@ int orc_intersect_triangle(const FfTriangle* tri, const FfRay* ray, FfIntersect*
     return 0;
 }
 
+int orc_intersect_sphere(const FfGeometry* sphere, const FfRay* ray, FfIntersect* out)
+{
+    /* SPHERE: the reference declares the type and the radius (U:193-195, U:227) and only printf's at K:166-169.
+     * Build-defined: object-space sphere of radius m_sphereRadius about the origin, two-sided (a ray that starts inside
+     * hits the far side), same EPSILON as the triangle test, unit normal P / r (reciprocal then multiply, like glm). */
+    const float* o = &ray->m_origin.x;
+    const float* d = &ray->m_direction.x;
+    const float EPSILON = 0.000001; /* the triangle test's constant (K:38) */
+    const float rad = sphere->m_sphereRadius;
+    const float b = orc_dot3(o, d);
+    const float c = orc_dot3(o, o) - rad * rad;
+    const float disc = b * b - c;
+    if (!(disc >= 0.0f)) return 0;
+    const float sq = sqrtf(disc);
+    float t = -b - sq;
+    if (!(t > EPSILON)) {
+        t = -b + sq;
+        if (!(t > EPSILON)) return 0;
+    }
+    out->m_intersectionPoint.x = o[0] + d[0] * t;
+    out->m_intersectionPoint.y = o[1] + d[1] * t;
+    out->m_intersectionPoint.z = o[2] + d[2] * t;
+    out->m_t = t;
+    const float inv = 1.0f / rad;
+    out->m_normal.x = out->m_intersectionPoint.x * inv;
+    out->m_normal.y = out->m_intersectionPoint.y * inv;
+    out->m_normal.z = out->m_intersectionPoint.z * inv;
+    return 1;
+}
+
 int orc_set_intersection(float* tMax, FfIntersect* out, const FfIntersect* obj, const float* model, const FfRay* ray)
 {
     /* K:110-125 */
@@ -488,8 +518,15 @@ static void intersect_rays_counted(const FfRay* ray, const FfGeometry* geoms, in
                 }
             }
             if (ctr) ctr->plane_tests += 1;
+        } else if (g->m_geometryType == FF_GEOM_SPHERE) {            /* K:166-169 only printf's: build-defined */
+            if (orc_intersect_sphere(g, &osr, &osi)) {
+                if (orc_set_intersection(&tMax, &isect, &osi, g->m_modelMatrix.m, ray)) {
+                    isect.geometryIndex = i;
+                    isect.triangleIndex = -1;
+                }
+            }
+            if (ctr) ctr->plane_tests += 1;
         }
-        /* SPHERE / other: the reference only printf's (K:166-173) */
     }
     if (ctr) ctr->rays += 1;
     *out = isect;
@@ -668,6 +705,14 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
                 float e1[3] = { tr->m_v1.x - tr->m_v0.x, tr->m_v1.y - tr->m_v0.y, tr->m_v1.z - tr->m_v0.z };
                 float e2[3] = { tr->m_v2.x - tr->m_v0.x, tr->m_v2.y - tr->m_v0.y, tr->m_v2.z - tr->m_v0.z };
                 orc_cross3(e1, e2, nobj);
+            } else if (hg->m_geometryType == FF_GEOM_SPHERE) {
+                /* the object-space unit normal of the hit: intersect the winning sphere again (same arithmetic, same result) */
+                FfRay osr;
+                FfIntersect osi;
+                object_space_ray(hg, &ray, &osr);
+                memset(&osi, 0, sizeof osi);
+                orc_intersect_sphere(hg, &osr, &osi);
+                nobj[0] = osi.m_normal.x; nobj[1] = osi.m_normal.y; nobj[2] = osi.m_normal.z;
             } else {
                 nobj[0] = hg->m_normal.x; nobj[1] = hg->m_normal.y; nobj[2] = hg->m_normal.z;
             }

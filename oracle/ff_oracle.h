@@ -57,6 +57,7 @@ void orc_camera_ray_matrix(const FfCamera* c, float* out16);              /* ker
 /* ---- device functions of the reference ---- */
 int orc_intersect_plane(const FfGeometry* plane, const FfRay* ray, FfIntersect* out);       /* kernel.cu:8-32 */
 int orc_intersect_triangle(const FfTriangle* tri, const FfRay* ray, FfIntersect* out);      /* kernel.cu:35-108 */
+int orc_intersect_sphere(const FfGeometry* sphere, const FfRay* ray, FfIntersect* out);     /* build-defined (kernel.cu:166-169 only printf's) */
 int orc_set_intersection(float* t_max, FfIntersect* out, const FfIntersect* obj, const float* model16,
                          const FfRay* ray);                                                 /* kernel.cu:110-125 */
 void orc_intersect_rays(const FfRay* ray, const FfGeometry* geoms, int n, FfIntersect* out);/* kernel.cu:127-176 */

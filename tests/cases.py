@@ -39,6 +39,9 @@ CASES = {
     "path_cornell_40x30_b1_s1": (scenes.cornell_wahoo_scene, "default", lambda: _path(40, 30, 1, 1)),
     # BXDFTyp::MIRROR (build-defined): mirror back wall + mirror cube, long specular chains
     "path_mirror_80x60_b6_s3": (scenes.cornell_mirror_scene, "inside", lambda: _path(80, 60, 6, 3, seed=77)),
+    # SPHERE geometry (build-defined): diffuse, non-uniformly scaled and mirror spheres; also through the reference's shade
+    "path_spheres_80x60_b5_s3": (scenes.cornell_spheres_scene, "inside", lambda: _path(80, 60, 5, 3, seed=5)),
+    "dbg_spheres_96x72": (scenes.cornell_spheres_scene, "inside", lambda: _dbg(96, 72)),
 }
 
 

@@ -86,12 +86,23 @@ def _random_rays(n, seed, inside_box):
 
 
 @pytest.mark.parametrize("mode", [T.TRACE_BVH, T.TRACE_BRUTE_FORCE], ids=["bvh", "brute"])
-@pytest.mark.parametrize("scene_name", ["cornell", "reference_wahoo"])
+@pytest.mark.parametrize("scene_name", ["cornell", "reference_wahoo", "spheres"])
 def test_intersect_rays_vs_oracle(tracer, scene_name, mode):
     """intersectRays (kernel.cu:127-176) on arbitrary rays: every field of Intersect must match the oracle exactly."""
     if scene_name == "cornell":
         scene = scenes.cornell_wahoo_scene()
         o, d = _random_rays(1500, 11, inside_box=True)
+    elif scene_name == "spheres":
+        # SPHERE geometries: rays from everywhere in the box, a third of them starting INSIDE one of the spheres (far-side
+        # hits), some aimed at the silhouettes (grazing discriminants)
+        scene = scenes.cornell_spheres_scene()
+        o, d = _random_rays(2400, 13, inside_box=True)
+        centres = np.array([(-1.3, -1.7, 0.3), (1.4, -1.9, 0.8), (0.9, 0.4, -1.2)], dtype=np.float32)
+        rng = np.random.default_rng(14)
+        o[:800] = centres[rng.integers(0, 3, 800)] + (rng.normal(size=(800, 3)) * 0.15).astype(np.float32)
+        aim = centres[rng.integers(0, 3, 400)] + (rng.normal(size=(400, 3)) * 0.45).astype(np.float32)
+        dd = aim - o[800:1200]
+        d[800:1200] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
     else:
         scene = scenes.reference_scene(scenes.load_mesh("wahoo"))
         o, d = _random_rays(1500, 12, inside_box=False)

@@ -70,12 +70,16 @@ def test_null_and_invalid_arguments_are_status_codes(ff):
 def test_unsupported_and_malformed_scenes(ff):
     lib = ff.load()
     info = T.FfSceneInfo()
-    # SPHERE: the reference only printf's (kernel.cu:166-169)
+    # SPHERE (the reference only printf's, kernel.cu:166-169) is a supported geometry; its radius must be positive
     g = (T.FfGeometry * 1)()
     lib.ff_geometry_init(C.byref(g[0]), T.GEOM_SPHERE, T.FfVec3(), T.FfVec3(), T.FfVec3(1, 1, 1), None, 0, 2.0)
     assert g[0].m_sphereRadius == 2.0
     bx = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 1, 1))
     g[0].m_bxdf = C.pointer(bx)
+    assert lib.ff_scene_info(g, 1, C.byref(info)) == T.FF_OK and info.num_geometries == 1 and info.num_meshes == 0
+    g[0].m_sphereRadius = 0.0
+    assert lib.ff_scene_info(g, 1, C.byref(info)) == T.FF_ERR_INVALID_ARG
+    g[0].m_geometryType = 7  # not a geometry type (kernel.cu:170-173)
     assert lib.ff_scene_info(g, 1, C.byref(info)) == T.FF_ERR_UNSUPPORTED
     # null BXDF: the reference memcpy's from it unconditionally (kernel.cu:282)
     lib.ff_geometry_init(C.byref(g[0]), T.GEOM_PLANE, T.FfVec3(), T.FfVec3(), T.FfVec3(1, 1, 1), None, 0, 0.0)

@@ -83,3 +83,18 @@ def test_scene_file_mirror_bxdf(tmp_path):
     assert b.m_type == T.BXDF_MIRROR
     assert (b.m_specularColor.x, b.m_specularColor.y, b.m_specularColor.z) == pytest.approx((0.9, 0.8, 0.7))
     sf.close()
+
+
+def test_scene_file_sphere(tmp_path):
+    p = tmp_path / "s.scene"
+    p.write_text("bxdf d diffuse albedo 0.5 0.5 0.5\nsphere radius 0.75 position 1 2 3 scale 1 2 1 bxdf d\n")
+    sf = lib.SceneFile(str(p))
+    g = sf.geometries[0]
+    assert g.m_geometryType == T.GEOM_SPHERE and g.m_sphereRadius == 0.75
+    assert (g.m_position.x, g.m_position.y, g.m_position.z) == (1.0, 2.0, 3.0)
+    assert lib.scene_info(sf).valid == 1
+    sf.close()
+    p.write_text("bxdf d diffuse\nsphere position 0 0 0 bxdf d\n")
+    with pytest.raises(lib.FireflyError) as e:
+        lib.SceneFile(str(p))
+    assert "sphere needs a radius" in e.value.message
