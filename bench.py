@@ -219,7 +219,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, world),
-                "kernel": "trace_bvh_kernel<false,1024>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
+                "kernel": "trace_bvh_kernel<false,1024,false>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
                 "algorithmic_bytes_per_launch": int(algo_bytes_launch),
                 "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
                             "tris": round(counted.tris_tested / max(1, counted.rays_traced), 3)},

@@ -26,7 +26,7 @@ struct FfState {
     GeomRecord* d_geoms = nullptr;
     TriRecord* d_tris = nullptr;
     BvhNode* d_nodes = nullptr;
-    int num_geoms = 0, num_planes = 0, num_nodes = 0, max_depth = 0;
+    int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
     uint64_t num_tris = 0;
     bool has_scene = false;
     // scene bookkeeping for updates (ff_update_transforms / ff_update_mesh)
@@ -195,6 +195,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.leaf_threshold = s->leaf_threshold;
     k.num_geoms = s->num_geoms;
     k.num_planes = s->num_planes;
+    k.num_quads = s->num_quads;
     k.geoms = s->d_geoms;
     k.tris = s->d_tris;
     k.nodes = s->d_nodes;
@@ -437,8 +438,11 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
     s->h_geoms = cs.geoms;
     s->num_geoms = (int)cs.geoms.size();
-    s->num_planes = 0;
-    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records
+    s->num_planes = s->num_quads = 0;
+    for (const GeomRecord& g : cs.geoms) {
+        s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records: planes, then spheres
+        s->num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
+    }
     s->num_tris = cs.total_tris;
     s->scene_builder = FF_BUILD_GPU_LBVH;
     refresh_scene_extent(s);
@@ -490,8 +494,11 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     s->build_stats.copy_ms = ms_since(t_copy);
     s->num_geoms = (int)cs.geoms.size();
-    s->num_planes = 0;
-    for (const GeomRecord& g : cs.geoms) s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records
+    s->num_planes = s->num_quads = 0;
+    for (const GeomRecord& g : cs.geoms) {
+        s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records: planes, then spheres
+        s->num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
+    }
     s->num_tris = cs.tris.size();
     s->node_capacity = cs.nodes.size();
     // Each mesh's nodes are contiguous with the root first: slot = [root, next mesh's root).
@@ -750,6 +757,7 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.n = n;
     p.num_geoms = s->num_geoms;
     p.num_planes = s->num_planes;
+    p.num_quads = s->num_quads;
     p.geoms = s->d_geoms;
     p.tris = s->d_tris;
     p.nodes = s->d_nodes;

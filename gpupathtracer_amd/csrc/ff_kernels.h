@@ -43,7 +43,8 @@ struct KParams {
     int pool_slots, pool_refill, pool_low;
     // scene
     int num_geoms;
-    int num_planes;  // records [0, num_planes) are planes, the rest meshes (processing order)
+    int num_planes;  // records [0, num_planes) are analytic shapes (planes, then spheres), the rest meshes (processing order)
+    int num_quads;   // records [0, num_quads) are the planes among them
     const GeomRecord* geoms;
     const TriRecord* tris;
     const BvhNode* nodes;
@@ -63,6 +64,7 @@ struct RayBatchParams {
     int n;
     int num_geoms;
     int num_planes;
+    int num_quads;
     const GeomRecord* geoms;
     const TriRecord* tris;
     const BvhNode* nodes;

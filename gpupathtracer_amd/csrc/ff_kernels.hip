@@ -234,11 +234,13 @@ struct Lds {
     int stack_base; // uint index of this lane's stack slot 0 (in units of 4 bytes from ff_smem)
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
+    int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
 };
 
-__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid)
+__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid, int num_quads)
 {
     Lds L;
+    L.num_quads = num_quads;
     L.node_count = lds_nodes;
     L.stride = block;
     L.stack_base = lds_nodes * 16 + tid;
@@ -416,7 +418,7 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
         H.cz = e1x * e2y - e2x * e1y;
     } else {
         const float4 pn = lds_geom4(L, g, 11);
-        if (lds_geom_i4(L, g, 16).x == FF_GEOM_SPHERE) {
+        if (g >= L.num_quads) {
             t = sphere_t(pn.w, osr);
             sphere_normal(pn.w, osr, t, H.cx, H.cy, H.cz);
         } else {
@@ -517,7 +519,7 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
         const int g = __ffs((int)quads) - 1;
         quads &= quads - 1u;
         if (STATS) { cnt.planes += 1; probe_round(cnt.plane_rounds); }
-        if (lds_geom_i4(L, g, 16).x == FF_GEOM_SPHERE) {
+        if (g >= L.num_quads) {
             // spheres have no screening form: the exact test runs here and yields the approximate world distance
             Ray osr;
             float len;
@@ -1163,12 +1165,14 @@ __device__ __forceinline__ void init_path(Path& P)
 // quorum while others kept traversing was measured slower on MI355X: the setup block is too large to run at partial
 // occupancy, see DESIGN.md.)  Latency is hidden by occupancy: 1024 threads per workgroup = 4 waves per SIMD.
 
-template <bool STATS, int BLOCK>
+// SPHERES = false is the instantiation for scenes without SPHERE geometries: the plane/sphere boundary becomes a
+// compile-time "never", so the sphere code drops out of the kernel (it costs 2 % otherwise, measured).
+template <bool STATS, int BLOCK, bool SPHERES>
 __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, SPHERES ? p.num_quads : 0x7fffffff);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1280,7 +1284,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, p.num_quads);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
     const int P = p.pool_slots;
@@ -1452,7 +1456,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
         const bool hit = best.geom >= 0;
         MaterialRef M;
         M.global = hit ? &p.geoms[best.geom] : p.geoms;
-        M.lds = make_lds(0, 0, kBlockThreads, tid);
+        M.lds = make_lds(0, 0, kBlockThreads, tid, 0);
         M.g = 0;
         active = shade_and_advance(p, best, hit, M, P);
     }
@@ -1464,7 +1468,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatchParams p)
 {
     const int tid = threadIdx.x;
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, kBlockThreads, tid);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads);
     if (MODE == FF_TRACE_BVH) stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);
     const int i = blockIdx.x * kBlockThreads + tid;
@@ -1611,12 +1615,18 @@ hipError_t prepare_kernels()
     if (e != hipSuccess) return e;
     // Only the BVH kernels go past the 64 KiB default (node cache + stacks + geometry records); the brute-force kernels
     // use a 48 KiB batch buffer plus a little static LDS, and asking for 160 KiB on top of static LDS is rejected.
-    FF_SET_LDS((trace_bvh_kernel<false, 512>))
-    FF_SET_LDS((trace_bvh_kernel<true, 512>))
-    FF_SET_LDS((trace_bvh_kernel<false, 768>))
-    FF_SET_LDS((trace_bvh_kernel<true, 768>))
-    FF_SET_LDS((trace_bvh_kernel<false, 1024>))
-    FF_SET_LDS((trace_bvh_kernel<true, 1024>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, false>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true>))
+    FF_SET_LDS((trace_bvh_kernel<true, 512, false>))
+    FF_SET_LDS((trace_bvh_kernel<true, 512, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, false>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true>))
+    FF_SET_LDS((trace_bvh_kernel<true, 768, false>))
+    FF_SET_LDS((trace_bvh_kernel<true, 768, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, false>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true>))
+    FF_SET_LDS((trace_bvh_kernel<true, 1024, false>))
+    FF_SET_LDS((trace_bvh_kernel<true, 1024, true>))
     FF_SET_LDS((trace_pool_kernel<false, 1024>))
     FF_SET_LDS((trace_pool_kernel<true, 1024>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
@@ -1636,16 +1646,21 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
             return hipGetLastError();
         }
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
-        if (block_threads == 1024) {
-            if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 1024>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((trace_bvh_kernel<false, 1024>), grid, block, lds, stream, p);
-        } else if (block_threads == 768) {
-            if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 768>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((trace_bvh_kernel<false, 768>), grid, block, lds, stream, p);
-        } else {
-            if (collect_stats) hipLaunchKernelGGL((trace_bvh_kernel<true, 512>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((trace_bvh_kernel<false, 512>), grid, block, lds, stream, p);
-        }
+        const bool spheres = p.num_planes > p.num_quads;
+#define FF_LAUNCH_BVH(B)                                                                                                  \
+    do {                                                                                                                  \
+        if (collect_stats) {                                                                                              \
+            if (spheres) hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p);              \
+            else hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p);                     \
+        } else {                                                                                                          \
+            if (spheres) hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p);             \
+            else hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p);                    \
+        }                                                                                                                 \
+    } while (0)
+        if (block_threads == 1024) FF_LAUNCH_BVH(1024);
+        else if (block_threads == 768) FF_LAUNCH_BVH(768);
+        else FF_LAUNCH_BVH(512);
+#undef FF_LAUNCH_BVH
     } else {
         const size_t lds = (size_t)kBruteBatchTris * sizeof(TriRecord);
         const dim3 block(kBlockThreads);

@@ -405,7 +405,7 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
     std::stable_sort(out.geoms.begin(), out.geoms.end(), [](const GeomRecord& a, const GeomRecord& b) {
         const bool pa = a.type != FF_GEOM_TRIANGLEMESH, pb = b.type != FF_GEOM_TRIANGLEMESH;
         if (pa != pb) return pa;
-        if (pa) return false;
+        if (pa) return a.type == FF_GEOM_PLANE && b.type != FF_GEOM_PLANE; // planes before spheres
         return a.tri_count < b.tri_count;
     });
     return FF_OK;
