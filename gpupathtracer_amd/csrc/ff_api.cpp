@@ -27,6 +27,7 @@ struct FfState {
     TriRecord* d_tris = nullptr;
     BvhNode* d_nodes = nullptr;
     int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
+    bool has_specular = false;
     uint64_t num_tris = 0;
     bool has_scene = false;
     // scene bookkeeping for updates (ff_update_transforms / ff_update_mesh)
@@ -196,6 +197,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.num_geoms = s->num_geoms;
     k.num_planes = s->num_planes;
     k.num_quads = s->num_quads;
+    k.has_specular = s->has_specular ? 1 : 0;
     k.geoms = s->d_geoms;
     k.tris = s->d_tris;
     k.nodes = s->d_nodes;
@@ -443,6 +445,8 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
         s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records: planes, then spheres
         s->num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
     }
+    s->has_specular = false;
+    for (const GeomRecord& g : cs.geoms) s->has_specular = s->has_specular || g.bxdf_type == FF_BXDF_MIRROR || g.bxdf_type == FF_BXDF_GLASS;
     s->num_tris = cs.total_tris;
     s->scene_builder = FF_BUILD_GPU_LBVH;
     refresh_scene_extent(s);
@@ -499,6 +503,8 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
         s->num_planes += g.type != FF_GEOM_TRIANGLEMESH ? 1 : 0; // analytic shapes lead the records: planes, then spheres
         s->num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
     }
+    s->has_specular = false;
+    for (const GeomRecord& g : cs.geoms) s->has_specular = s->has_specular || g.bxdf_type == FF_BXDF_MIRROR || g.bxdf_type == FF_BXDF_GLASS;
     s->num_tris = cs.tris.size();
     s->node_capacity = cs.nodes.size();
     // Each mesh's nodes are contiguous with the root first: slot = [root, next mesh's root).
@@ -550,6 +556,8 @@ int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
     FF_HIP(hipMemcpyAsync(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice, s->stream));
     FF_HIP(hipStreamSynchronize(s->stream));
     s->h_geoms = cs.geoms;
+    s->has_specular = false; // materials may have changed
+    for (const GeomRecord& g : cs.geoms) s->has_specular = s->has_specular || g.bxdf_type == FF_BXDF_MIRROR || g.bxdf_type == FF_BXDF_GLASS;
     s->build_stats.last_operation = 3;
     s->build_stats.total_ms = ms_since(t_call);
     s->build_stats.copy_ms = s->build_stats.total_ms;

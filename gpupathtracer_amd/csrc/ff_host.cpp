@@ -374,6 +374,8 @@ int ff_scene_file_load(const char* path, FfSceneFile** out_scene)
                 if (key == "albedo") { if (!read_floats(tok, i, 3, v)) bad("albedo needs 3 numbers"); else b->m_albedo = FfVec3{ v[0], v[1], v[2] }; }
                 else if (key == "color") { if (!read_floats(tok, i, 3, v)) bad("color needs 3 numbers"); else b->m_emissiveColor = FfVec3{ v[0], v[1], v[2] }; }
                 else if (key == "specular") { if (!read_floats(tok, i, 3, v)) bad("specular needs 3 numbers"); else b->m_specularColor = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "transmittance") { if (!read_floats(tok, i, 3, v)) bad("transmittance needs 3 numbers"); else b->m_transmittanceColor = FfVec3{ v[0], v[1], v[2] }; }
+                else if (key == "ior") { if (!read_floats(tok, i, 1, v)) bad("ior needs a number"); else b->m_refractiveIndex = v[0]; }
                 else if (key == "intensity") { if (!read_floats(tok, i, 1, v)) bad("intensity needs a number"); else b->m_intensity = v[0]; }
                 else bad("unknown bxdf key");
             }

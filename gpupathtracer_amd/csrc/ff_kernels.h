@@ -45,6 +45,7 @@ struct KParams {
     int num_geoms;
     int num_planes;  // records [0, num_planes) are analytic shapes (planes, then spheres), the rest meshes (processing order)
     int num_quads;   // records [0, num_quads) are the planes among them
+    int has_specular; // some surface is MIRROR or GLASS
     const GeomRecord* geoms;
     const TriRecord* tris;
     const BvhNode* nodes;

@@ -1037,6 +1037,8 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
 
 // Shade the finished segment and advance the path.  Returns true when the lane still owns its pixel (either the path
 // continues with a new ray in P.ray, or the next sample's primary ray was generated), false when the pixel is finished.
+// SPECULAR = false: the caller guarantees a scene without MIRROR / GLASS surfaces and their code drops out.
+template <bool SPECULAR = true>
 __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
 {
     const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
@@ -1057,19 +1059,63 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
             Ly = 0.f + P.by * emission.y;
             Lz = 0.f + P.bz * emission.z;
         } else {
-            // MIRROR: perfect reflection, throughput *= m_specularColor (the record's tint slot holds it); everything else is
-            // diffuse (utilities.h:109): cosine-weighted sampling, so f*cos/pdf = albedo
-            const bool mirror = mat_bxdf(M) == FF_BXDF_MIRROR;
+            // MIRROR: perfect reflection, throughput *= m_specularColor (the record's tint slot holds it).  GLASS: smooth
+            // dielectric, Fresnel-weighted choice between reflection and refraction (oracle/ff_oracle.c is the definition).
+            // Everything else is diffuse (utilities.h:109): cosine-weighted sampling, so f*cos/pdf = albedo.
+            const int bxdf = mat_bxdf(M);
+            const bool mirror = SPECULAR && bxdf == FF_BXDF_MIRROR, glass = SPECULAR && bxdf == FF_BXDF_GLASS;
             const float4 albedo = mat_f4(M, 12);
-            P.bx = P.bx * albedo.x;
-            P.by = P.by * albedo.y;
-            P.bz = P.bz * albedo.z;
+            if (!glass) {
+                P.bx = P.bx * albedo.x;
+                P.by = P.by * albedo.y;
+                P.bz = P.bz * albedo.z;
+            }
             if (P.b != p.bounces - 1) {
                 const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
                 float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
-                if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; }
+                bool flipped = false;
+                if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; flipped = true; }
                 float wox, woy, woz;
-                if (mirror) {
+                float sx = ux, sy = uy, sz = uz; // the next ray starts on this side of the surface
+                if (glass) {
+                    const float dx = P.ray.dx, dy = P.ray.dy, dz = P.ray.dz;
+                    const float ior = albedo.w;
+                    const float eta = flipped ? ior : 1.0f / ior;
+                    const float ci = -dot3(ux, uy, uz, dx, dy, dz);
+                    const float s2 = (eta * eta) * (1.0f - ci * ci);
+                    bool reflect = true;
+                    float ct = 0.f;
+                    if (s2 < 1.0f) {
+                        ct = sqrtf(1.0f - s2);
+                        const float a = eta * ci, bq = eta * ct;
+                        const float rs = (a - ct) / (a + ct), rp = (ci - bq) / (ci + bq);
+                        const float F = 0.5f * (rs * rs + rp * rp);
+                        unsigned r0, r1;
+                        const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
+                        philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
+                        const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
+                        reflect = u1 < F;
+                    }
+                    float tx, ty, tz;
+                    if (reflect) {
+                        const float k2 = 2.0f * ci;
+                        wox = dx + k2 * ux;
+                        woy = dy + k2 * uy;
+                        woz = dz + k2 * uz;
+                        tx = albedo.x; ty = albedo.y; tz = albedo.z;
+                    } else {
+                        const float k = eta * ci - ct;
+                        wox = eta * dx + k * ux;
+                        woy = eta * dy + k * uy;
+                        woz = eta * dz + k * uz;
+                        const float4 tr = mat_f4(M, 13);
+                        tx = tr.x; ty = tr.y; tz = tr.z;
+                        sx = -ux; sy = -uy; sz = -uz;
+                    }
+                    P.bx = P.bx * tx;
+                    P.by = P.by * ty;
+                    P.bz = P.bz * tz;
+                } else if (mirror) {
                     const float k2 = 2.0f * dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz);
                     wox = P.ray.dx - k2 * ux;
                     woy = P.ray.dy - k2 * uy;
@@ -1091,9 +1137,9 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                     woy = (t1 * wlx + s1 * wly) + uy * wlz;
                     woz = (t2 * wlx + s2 * wly) + uz * wlz;
                 }
-                P.ray.ox = best.px + ux * kRayEps;
-                P.ray.oy = best.py + uy * kRayEps;
-                P.ray.oz = best.pz + uz * kRayEps;
+                P.ray.ox = best.px + sx * kRayEps;
+                P.ray.oy = best.py + sy * kRayEps;
+                P.ray.oz = best.pz + sz * kRayEps;
                 P.ray.dx = wox; // unit local direction in an orthonormal basis: used as is (|wo| = 1 +- 1e-6)
                 P.ray.dy = woy;
                 P.ray.dz = woz;
@@ -1165,14 +1211,15 @@ __device__ __forceinline__ void init_path(Path& P)
 // quorum while others kept traversing was measured slower on MI355X: the setup block is too large to run at partial
 // occupancy, see DESIGN.md.)  Latency is hidden by occupancy: 1024 threads per workgroup = 4 waves per SIMD.
 
-// SPHERES = false is the instantiation for scenes without SPHERE geometries: the plane/sphere boundary becomes a
-// compile-time "never", so the sphere code drops out of the kernel (it costs 2 % otherwise, measured).
-template <bool STATS, int BLOCK, bool SPHERES>
+// EXTRAS = false is the instantiation for scenes made of what the reference itself renders (planes and meshes, diffuse
+// and emitting surfaces): the plane/sphere boundary becomes a compile-time "never" and the MIRROR / GLASS branches of the
+// shader drop out (together they cost the reference-like scenes 3.5 % otherwise, measured on one box).
+template <bool STATS, int BLOCK, bool EXTRAS>
 __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, SPHERES ? p.num_quads : 0x7fffffff);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1207,7 +1254,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             M.global = nullptr;
             M.lds = L;
             M.g = best.geom;
-            active = shade_and_advance(p, best, hit, M, P);
+            active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
             inflight = false;
         }
         if (STATS) t2 = __builtin_amdgcn_s_memtime();
@@ -1646,7 +1693,7 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
             return hipGetLastError();
         }
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
-        const bool spheres = p.num_planes > p.num_quads;
+        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0; // any build-defined extra: the full kernel
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
         if (collect_stats) {                                                                                              \

@@ -363,6 +363,14 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
         r.emission[0] = b.m_emissiveColor.x * b.m_intensity; // utilities.h:102
         r.emission[1] = b.m_emissiveColor.y * b.m_intensity;
         r.emission[2] = b.m_emissiveColor.z * b.m_intensity;
+        if (b.m_type == FF_BXDF_GLASS) {
+            // a dielectric neither emits nor has an albedo: the two colour slots carry m_specularColor (reflection) and
+            // m_transmittanceColor (refraction), the spare lane of the first one the refractive index
+            if (!(b.m_refractiveIndex > 0.f)) return fail(FF_ERR_INVALID_ARG, "geometry %d: glass needs a positive m_refractiveIndex", i);
+            r.albedo[0] = b.m_specularColor.x; r.albedo[1] = b.m_specularColor.y; r.albedo[2] = b.m_specularColor.z;
+            r.albedo[3] = b.m_refractiveIndex;
+            r.emission[0] = b.m_transmittanceColor.x; r.emission[1] = b.m_transmittanceColor.y; r.emission[2] = b.m_transmittanceColor.z;
+        }
         r.type = g.m_geometryType;
         r.bxdf_type = b.m_type;
         r.bvh_root = -1;

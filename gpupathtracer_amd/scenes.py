@@ -55,10 +55,13 @@ def subdivide_sphere(tris, levels):
     return out
 
 
-def make_bxdf(kind, albedo=(-1, -1, -1), emissive=(-1, -1, -1), intensity=-1.0, specular=(-1, -1, -1)):
+def make_bxdf(kind, albedo=(-1, -1, -1), emissive=(-1, -1, -1), intensity=-1.0, specular=(-1, -1, -1),
+              transmittance=(-1, -1, -1), ior=-1.0):
     b = T.FfBXDF()
     L.load().ff_bxdf_init(C.byref(b))  # utilities.h:81-88 defaults
     b.m_specularColor = T.FfVec3(*specular)
+    b.m_transmittanceColor = T.FfVec3(*transmittance)
+    b.m_refractiveIndex = ior
     b.m_type = kind
     b.m_albedo = T.FfVec3(*albedo)
     b.m_emissiveColor = T.FfVec3(*emissive)
@@ -190,6 +193,20 @@ def cornell_spheres_scene(cube=None):
     s.add_sphere(0.8, (-1.3, -1.7, 0.3), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.2, 0.5, 0.9)))
     s.add_sphere(0.5, (1.4, -1.9, 0.8), (20, 0, 35), (1.6, 1.0, 1.2), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.9, 0.6, 0.1)))
     s.add_sphere(0.6, (0.9, 0.4, -1.2), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_MIRROR, specular=(0.95, 0.95, 0.95)))
+    return s.finalize()
+
+
+def cornell_glass_scene(cube=None):
+    """The C2 box with GLASS surfaces (BXDFTyp::GLASS, utilities.h:68-75): a glass sphere, a glass pane (a two-sided
+    plane) in front of a diffuse cube, and a mirror sphere behind."""
+    cube = load_mesh("cube") if cube is None else cube
+    glass = dict(specular=(1.0, 1.0, 1.0), transmittance=(0.95, 0.98, 0.95), ior=1.5)
+    s = Scene()
+    s.add_mesh(cube, (1.1, -2.0, -0.8), (0, 25, 0), (1, 1, 1), make_bxdf(T.BXDF_DIFFUSE, albedo=(0.8, 0.3, 0.2)))
+    _box(s)
+    s.add_sphere(0.85, (-0.9, -1.65, 0.4), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_GLASS, **glass))
+    s.add_plane((1.0, -1.2, 0.6), (0, 20, 0), (1.8, 2.4, 1), make_bxdf(T.BXDF_GLASS, specular=(1, 1, 1), transmittance=(0.8, 0.9, 1.0), ior=1.33))
+    s.add_sphere(0.5, (-1.2, 0.9, -1.4), (0, 0, 0), (1, 1, 1), make_bxdf(T.BXDF_MIRROR, specular=(0.9, 0.9, 0.9)))
     return s.finalize()
 
 

@@ -209,7 +209,7 @@ FF_API void ff_free_triangles(FfTriangle* triangles);
  * one statement per line, '#' starts a comment:
  *
  *   camera position X Y Z yaw DEG pitch DEG fov DEG near N far F            (every key optional: kernel.cu:312-321 defaults)
- *   bxdf NAME diffuse|emitter|mirror|glass [albedo R G B] [specular R G B] [color R G B] [intensity I]
+ *   bxdf NAME diffuse|emitter|mirror|glass [albedo R G B] [specular R G B] [transmittance R G B] [ior N] [color R G B] [intensity I]
  *   mesh FILE.obj [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME (path relative to the scene file)
  *   plane [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME
  *   sphere radius R [position X Y Z] [rotation X Y Z] [scale X Y Z] bxdf NAME

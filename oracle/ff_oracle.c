@@ -688,12 +688,18 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
             }
             /* MIRROR (U:68-75 declares it, U:108 leaves it as a TODO; build-defined): perfect specular reflection about the
              * shading normal, throughput *= m_specularColor, no random numbers consumed.
-             * Everything else (DIFFUSE, and GLASS, which falls through like U:109's constant-true test) is diffuse. */
+             * GLASS (same status): smooth dielectric of index m_refractiveIndex; the facing side decides entering/leaving,
+             * unpolarised Fresnel reflectance F, one uniform of the bounce's random pair picks reflection (probability F,
+             * throughput *= m_specularColor) or refraction (throughput *= m_transmittanceColor); total internal
+             * reflection reflects.  Everything else is diffuse (U:109's constant-true test). */
             const int mirror = bx->m_type == FF_BXDF_MIRROR;
-            const FfVec3 tint = mirror ? bx->m_specularColor : bx->m_albedo;
-            beta[0] = beta[0] * tint.x;
-            beta[1] = beta[1] * tint.y;
-            beta[2] = beta[2] * tint.z;
+            const int glass = bx->m_type == FF_BXDF_GLASS;
+            if (!glass) {
+                const FfVec3 tint = mirror ? bx->m_specularColor : bx->m_albedo;
+                beta[0] = beta[0] * tint.x;
+                beta[1] = beta[1] * tint.y;
+                beta[2] = beta[2] * tint.z;
+            }
             if (b == p->bounces - 1) break;
             /* Shading normal: the direction of inverse(transpose(M)) * n_obj, normalised once.  For triangles the
              * un-normalised face normal cross(e1, e2) is transformed (the reference's Intersect carries its normalised
@@ -723,9 +729,48 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
                 orc_mat4_mul_vec4(nm, n4, nw4);
             }
             orc_normalize3(nw4, nrm);
-            if (orc_dot3(nrm, &ray.m_direction.x) > 0.f) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+            int flipped = 0;
+            if (orc_dot3(nrm, &ray.m_direction.x) > 0.f) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; flipped = 1; }
             float wo[3];
-            if (mirror) {
+            float side[3] = { nrm[0], nrm[1], nrm[2] }; /* the next ray starts on this side of the surface */
+            if (glass) {
+                const float* d = &ray.m_direction.x;
+                const float ior = bx->m_refractiveIndex;
+                const float eta = flipped ? ior : 1.0f / ior; /* n_incident / n_transmitted: the geometric normal faces the outside */
+                const float ci = -orc_dot3(nrm, d);
+                const float s2 = (eta * eta) * (1.0f - ci * ci);
+                int reflect = 1;
+                float ct = 0.f;
+                if (s2 < 1.0f) {
+                    ct = sqrtf(1.0f - s2);
+                    const float a = eta * ci, bq = eta * ct;
+                    const float rs = (a - ct) / (a + ct), rp = (ci - bq) / (ci + bq);
+                    const float F = 0.5f * (rs * rs + rp * rp);
+                    float u1, u2;
+                    uint32_t k24;
+                    orc_sample_uniforms(pixel_index, (uint32_t)s, (uint32_t)b, p->seed, &u1, &u2, &k24);
+                    (void)u2; (void)k24;
+                    reflect = u1 < F;
+                }
+                FfVec3 tint;
+                if (reflect) {
+                    const float k2 = 2.0f * ci;
+                    wo[0] = d[0] + k2 * nrm[0];
+                    wo[1] = d[1] + k2 * nrm[1];
+                    wo[2] = d[2] + k2 * nrm[2];
+                    tint = bx->m_specularColor;
+                } else {
+                    const float k = eta * ci - ct;
+                    wo[0] = eta * d[0] + k * nrm[0];
+                    wo[1] = eta * d[1] + k * nrm[1];
+                    wo[2] = eta * d[2] + k * nrm[2];
+                    tint = bx->m_transmittanceColor;
+                    side[0] = -nrm[0]; side[1] = -nrm[1]; side[2] = -nrm[2];
+                }
+                beta[0] = beta[0] * tint.x;
+                beta[1] = beta[1] * tint.y;
+                beta[2] = beta[2] * tint.z;
+            } else if (mirror) {
                 /* wo = d - (2 (n.d)) n with the facing normal: the reflected direction keeps the length of d */
                 const float k2 = 2.0f * orc_dot3(nrm, &ray.m_direction.x);
                 wo[0] = ray.m_direction.x - k2 * nrm[0];
@@ -743,9 +788,9 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
                 wo[1] = (tt[1] * wl[0] + bb[1] * wl[1]) + nrm[1] * wl[2];
                 wo[2] = (tt[2] * wl[0] + bb[2] * wl[1]) + nrm[2] * wl[2];
             }
-            ray.m_origin.x = is.m_intersectionPoint.x + nrm[0] * ORC_RAY_EPS;
-            ray.m_origin.y = is.m_intersectionPoint.y + nrm[1] * ORC_RAY_EPS;
-            ray.m_origin.z = is.m_intersectionPoint.z + nrm[2] * ORC_RAY_EPS;
+            ray.m_origin.x = is.m_intersectionPoint.x + side[0] * ORC_RAY_EPS;
+            ray.m_origin.y = is.m_intersectionPoint.y + side[1] * ORC_RAY_EPS;
+            ray.m_origin.z = is.m_intersectionPoint.z + side[2] * ORC_RAY_EPS;
             ray.m_direction.x = wo[0]; ray.m_direction.y = wo[1]; ray.m_direction.z = wo[2];
         }
         acc[0] = acc[0] + L[0];

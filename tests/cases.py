@@ -42,6 +42,8 @@ CASES = {
     # SPHERE geometry (build-defined): diffuse, non-uniformly scaled and mirror spheres; also through the reference's shade
     "path_spheres_80x60_b5_s3": (scenes.cornell_spheres_scene, "inside", lambda: _path(80, 60, 5, 3, seed=5)),
     "dbg_spheres_96x72": (scenes.cornell_spheres_scene, "inside", lambda: _dbg(96, 72)),
+    # BXDFTyp::GLASS (build-defined): glass sphere (enter, leave, total internal reflection), glass pane, mirror sphere
+    "path_glass_80x60_b8_s4": (scenes.cornell_glass_scene, "inside", lambda: _path(80, 60, 8, 4, seed=31)),
 }
 
 

@@ -98,3 +98,13 @@ def test_scene_file_sphere(tmp_path):
     with pytest.raises(lib.FireflyError) as e:
         lib.SceneFile(str(p))
     assert "sphere needs a radius" in e.value.message
+
+
+def test_scene_file_glass_bxdf(tmp_path):
+    p = tmp_path / "g.scene"
+    p.write_text("bxdf g glass specular 1 1 1 transmittance 0.9 0.95 1 ior 1.5\nsphere radius 1 bxdf g\n")
+    sf = lib.SceneFile(str(p))
+    b = sf.geometries[0].m_bxdf.contents
+    assert b.m_type == T.BXDF_GLASS and b.m_refractiveIndex == 1.5
+    assert (b.m_transmittanceColor.x, b.m_transmittanceColor.y, b.m_transmittanceColor.z) == pytest.approx((0.9, 0.95, 1.0))
+    sf.close()
