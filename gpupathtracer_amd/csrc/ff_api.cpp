@@ -965,6 +965,18 @@ int ff_debug_counters(FfState* s, unsigned long long* out24)
     return FF_OK;
 }
 
+int ff_debug_check_ieee(FfState* s, unsigned long long* out_mismatches2)
+{
+    clear_error();
+    if (!s || !out_mismatches2) return fail(FF_ERR_INVALID_ARG, "ff_debug_check_ieee: null argument");
+    FF_HIP(hipSetDevice(s->device));
+    FF_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), s->stream));
+    FF_HIP(launch_ieee_check(s->d_counters, s->stream));
+    FF_HIP(hipMemcpyAsync(out_mismatches2, s->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    return FF_OK;
+}
+
 int ff_stats(FfState* s, FfStats* out)
 {
     clear_error();

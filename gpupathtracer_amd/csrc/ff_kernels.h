@@ -88,6 +88,9 @@ hipError_t launch_combine(const KParams& p, hipStream_t stream);
 hipError_t launch_accumulate(float* sum, const float* frame, float* mean, unsigned char* rgb8, size_t values, int first_frame, float inv_frames,
                              hipStream_t stream);
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream);
+// Compares the kernels' lean correctly-rounded 1/x and sqrt(x) with the IEEE expansions on all 2^32 inputs; adds the
+// mismatch counts to mismatches2[0] (reciprocal) and [1] (square root).
+hipError_t launch_ieee_check(unsigned long long* mismatches2, hipStream_t stream);
 hipError_t launch_deinterleave(const void* src, void* dst, int width, int height, int strip_rows, int num_parts, int elem_bytes,
                                hipStream_t stream);
 hipError_t prepare_kernels(); // one-time function attributes (dynamic LDS limit)

@@ -77,6 +77,32 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return (px + py) + pz;
 }
 
+// Correctly rounded 1/x and sqrt(x) (== the compiler's IEEE expansions, bit for bit, for every float: checked over all
+// 2^32 inputs by tools/diag/ieee_check.hip and tests/test_gpu_properties.py).  In the range 2^-60 .. 2^60, where every
+// operand of this renderer lives, one Newton step on the hardware estimate is already exact and replaces the 11 / 17
+// instruction expansions with their denormal scaling; outside the range the full expansion runs.
+__device__ __forceinline__ float ieee_rcp(float x)
+{
+    const unsigned a = __float_as_uint(x) & 0x7fffffffu;
+    if (__builtin_expect(a - 0x21800000u < 0x3c000000u, 1)) { // 2^-60 <= |x| < 2^60
+        const float y = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(e, y, y);
+    }
+    return 1.0f / x;
+}
+__device__ __forceinline__ float ieee_sqrt(float x)
+{
+    if (__builtin_expect(__float_as_uint(x) - 0x21800000u < 0x3c000000u, 1)) { // 2^-60 <= x < 2^60
+        const float r = __builtin_amdgcn_rsqf(x);
+        const float g = x * r, h = 0.5f * r;
+        const float e = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(e, h, g);
+    }
+    return sqrtf(x);
+}
+
+
 // kernel.cu:138 — Ray(invM * vec4(o,1), normalize(invM * vec4(d,0))).  `len` is |invM*d| before normalisation: an
 // object-space parameter t corresponds to the world distance t * |d_world| / len.
 __device__ __forceinline__ void object_space_ray(const GeomRecord& G, const Ray& r, Ray& o, float& len)
@@ -89,8 +115,8 @@ __device__ __forceinline__ void object_space_ray(const GeomRecord& G, const Ray&
     const float tz = (G.inv_c0[2] * r.dx + G.inv_c1[2] * r.dy) + (G.inv_c2[2] * r.dz + G.inv_c2[3]);
     // normalize(vec4) with w == +-0: dot4 = (x*x + y*y) + (z*z + 0)
     const float dd = (tx * tx + ty * ty) + tz * tz;
-    len = sqrtf(dd);
-    const float inv = 1.0f / len; // glm inversesqrt = 1 / sqrt
+    len = ieee_sqrt(dd);
+    const float inv = ieee_rcp(len); // glm inversesqrt = 1 / sqrt
     o.dx = tx * inv;
     o.dy = ty * inv;
     o.dz = tz * inv;
@@ -109,7 +135,7 @@ __device__ __forceinline__ void consider(const GeomRecord& G, int g, int rec, in
     const float d2 = (vx * vx + vy * vy) + vz * vz;
     // sqrt is monotonic: a squared distance clearly above the best one cannot win or tie; skip the IEEE sqrt for it
     if (d2 > best.dist * best.dist * 1.00001f) return;
-    const float dist = sqrtf(d2); // glm distance, kernel.cu:114
+    const float dist = ieee_sqrt(d2); // glm distance, kernel.cu:114
     bool take = dist < best.dist; // kernel.cu:115
     if (!take && dist == best.dist && best.geom >= 0) {
         const int bo = geoms[best.geom].orig_index;
@@ -165,7 +191,7 @@ __device__ __forceinline__ float triangle_t(const float4 A, const float4 E1, con
     const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz);                                                  // :70
     if (v < 0.0f || u + v > det) return -1.0f;                                                           // :71
     float t = dot3(e2x, e2y, e2z, qx, qy, qz);                                                           // :75
-    const float invDet = 1.0f / det; // :77 (a double division narrowed to float == the float division)
+    const float invDet = ieee_rcp(det); // :77 (a double division narrowed to float == the float division)
     t = t * invDet;                  // :79
     return t > kTriEpsilon ? t : -1.0f; // :97
 }
@@ -189,7 +215,7 @@ __device__ __forceinline__ float sphere_t(float rad, const Ray& r)
     const float c = dot3(r.ox, r.oy, r.oz, r.ox, r.oy, r.oz) - rad * rad;
     const float disc = b * b - c;
     if (!(disc >= 0.0f)) return -1.0f;
-    const float sq = sqrtf(disc);
+    const float sq = ieee_sqrt(disc);
     float t = -b - sq;
     if (!(t > kTriEpsilon)) {
         t = -b + sq;
@@ -201,7 +227,7 @@ __device__ __forceinline__ float sphere_t(float rad, const Ray& r)
 // Unit object-space normal of a sphere hit at parameter t: P * (1 / rad).
 __device__ __forceinline__ void sphere_normal(float rad, const Ray& r, float t, float& nx, float& ny, float& nz)
 {
-    const float inv = 1.0f / rad;
+    const float inv = ieee_rcp(rad);
     nx = (r.ox + r.dx * t) * inv;
     ny = (r.oy + r.dy * t) * inv;
     nz = (r.oz + r.dz * t) * inv;
@@ -301,8 +327,8 @@ __device__ __forceinline__ void object_space_ray_lds(const Lds& L, int g, const 
     const float ty = (c0.y * r.dx + c1.y * r.dy) + (c2.y * r.dz + c1.w);
     const float tz = (c0.z * r.dx + c1.z * r.dy) + (c2.z * r.dz + c2.w);
     const float dd = (tx * tx + ty * ty) + tz * tz;
-    len = sqrtf(dd);
-    const float inv = 1.0f / len;
+    len = ieee_sqrt(dd);
+    const float inv = ieee_rcp(len);
     o.dx = tx * inv;
     o.dy = ty * inv;
     o.dz = tz * inv;
@@ -435,7 +461,7 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
     H.wy = (m0.y * Px + m1.y * Py) + (m2.y * Pz + m3.y);
     H.wz = (m0.z * Px + m1.z * Py) + (m2.z * Pz + m3.z);
     const float vx = wr.ox - H.wx, vy = wr.oy - H.wy, vz = wr.oz - H.wz;
-    dist = sqrtf((vx * vx + vy * vy) + vz * vz); // kernel.cu:114
+    dist = ieee_sqrt((vx * vx + vy * vy) + vz * vz); // kernel.cu:114
     return true;
 }
 
@@ -698,7 +724,7 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
             float ta = tn * __builtin_amdgcn_rcpf(det); // approximate t (kernel.cu:77-79 is exact: 1/det, then multiply)
             if (ta < kTriEpsilon * 1.001f) {
                 if (ta > kTriEpsilon * 0.999f) {
-                    ta = tn * (1.0f / det); // within the margin of the t > EPSILON test: decide exactly (kernel.cu:97)
+                    ta = tn * ieee_rcp(det); // within the margin of the t > EPSILON test: decide exactly (kernel.cu:97)
                     ok = ta > kTriEpsilon;
                 } else {
                     ok = false;
@@ -868,7 +894,7 @@ __device__ __forceinline__ void world_normal(const MaterialRef& M, const Best& b
 {
     float ox = best.cx, oy = best.cy, oz = best.cz;
     if (best.rec >= 0 && unit_object_normal) {
-        const float inv = 1.0f / sqrtf(dot3(ox, oy, oz, ox, oy, oz));
+        const float inv = ieee_rcp(ieee_sqrt(dot3(ox, oy, oz, ox, oy, oz)));
         ox = ox * inv;
         oy = oy * inv;
         oz = oz * inv;
@@ -916,10 +942,10 @@ __device__ __forceinline__ void cosine_sample(float u1, unsigned k24, float& x, 
     if ((oct + 1u) & 2u) { sn = c; cs = s; } else { sn = s; cs = c; }
     if (oct >= 4u) sn = -sn;
     if (oct >= 2u && oct <= 5u) cs = -cs;
-    const float r = sqrtf(u1);
+    const float r = ieee_sqrt(u1);
     x = r * cs;
     y = r * sn;
-    z = sqrtf(fmaxf(0.0f, 1.0f - u1));
+    z = ieee_sqrt(fmaxf(0.0f, 1.0f - u1));
 }
 
 __device__ __forceinline__ unsigned char to_u8(float v)
@@ -967,7 +993,7 @@ __device__ __forceinline__ void primary_ray(const KParams& p, unsigned gxy, Ray&
     const float wy = (p.cam_c0[1] * v0 + p.cam_c1[1] * v1) + (p.cam_c2[1] * v2 + p.cam_c3[1] * v3);
     const float wz = (p.cam_c0[2] * v0 + p.cam_c1[2] * v1) + (p.cam_c2[2] * v2 + p.cam_c3[2] * v3);
     const float ddx = wx - p.cam_pos[0], ddy = wy - p.cam_pos[1], ddz = wz - p.cam_pos[2];
-    const float inv = 1.0f / sqrtf(dot3(ddx, ddy, ddz, ddx, ddy, ddz)); // :205
+    const float inv = ieee_rcp(ieee_sqrt(dot3(ddx, ddy, ddz, ddx, ddy, ddz))); // :205
     ray.ox = p.cam_pos[0];
     ray.oy = p.cam_pos[1];
     ray.oz = p.cam_pos[2];
@@ -1071,7 +1097,7 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                 P.bz = P.bz * albedo.z;
             }
             if (P.b != p.bounces - 1) {
-                const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+                const float ninv = ieee_rcp(ieee_sqrt(dot3(nx, ny, nz, nx, ny, nz)));
                 float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
                 bool flipped = false;
                 if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; flipped = true; }
@@ -1080,13 +1106,13 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                 if (glass) {
                     const float dx = P.ray.dx, dy = P.ray.dy, dz = P.ray.dz;
                     const float ior = albedo.w;
-                    const float eta = flipped ? ior : 1.0f / ior;
+                    const float eta = flipped ? ior : ieee_rcp(ior);
                     const float ci = -dot3(ux, uy, uz, dx, dy, dz);
                     const float s2 = (eta * eta) * (1.0f - ci * ci);
                     bool reflect = true;
                     float ct = 0.f;
                     if (s2 < 1.0f) {
-                        ct = sqrtf(1.0f - s2);
+                        ct = ieee_sqrt(1.0f - s2);
                         const float a = eta * ci, bq = eta * ct;
                         const float rs = (a - ct) / (a + ct), rp = (ci - bq) / (ci + bq);
                         const float F = 0.5f * (rs * rs + rp * rp);
@@ -1129,7 +1155,7 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
                     cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
                     // orthonormal basis (Duff et al. 2017)
                     const float sign = copysignf(1.0f, uz);
-                    const float aa = -1.0f / (sign + uz);
+                    const float aa = -ieee_rcp(sign + uz); // -1 / x == -(1 / x)
                     const float bb = (ux * uy) * aa;
                     const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
                     const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
@@ -1594,6 +1620,22 @@ __global__ void combine_kernel(const KParams p)
     }
 }
 
+// Exhaustive self-check of ieee_rcp / ieee_sqrt against the compiler's IEEE expansions: every float bit pattern.
+__global__ void ieee_check_kernel(unsigned long long* mismatches)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad_rcp = 0, bad_sqrt = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((unsigned)i);
+        const float a = ieee_rcp(x), ra = 1.0f / x;
+        const float b = ieee_sqrt(x), rb = sqrtf(x);
+        if (__float_as_uint(a) != __float_as_uint(ra) && !(a != a && ra != ra)) ++bad_rcp;
+        if (__float_as_uint(b) != __float_as_uint(rb) && !(b != b && rb != rb)) ++bad_sqrt;
+    }
+    if (bad_rcp) atomicAdd(&mismatches[0], bad_rcp);
+    if (bad_sqrt) atomicAdd(&mismatches[1], bad_sqrt);
+}
+
 // Progressive accumulation (ff_render_progressive): running sum of whole frames, output = sum * (1 / frames).
 __global__ void accumulate_kernel(float* __restrict__ sum, const float* __restrict__ frame, float* __restrict__ mean, unsigned char* __restrict__ rgb8,
                                   size_t values, int first_frame, float inv_frames)
@@ -1722,6 +1764,12 @@ hipError_t launch_combine(const KParams& p, hipStream_t stream)
     if (p.width <= 0 || p.local_rows <= 0) return hipSuccess;
     const dim3 block(256), grid((p.width + 255) / 256, p.local_rows);
     hipLaunchKernelGGL(combine_kernel, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ieee_check(unsigned long long* mismatches2, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ieee_check_kernel, dim3(256 * 8), dim3(256), 0, stream, mismatches2);
     return hipGetLastError();
 }
 

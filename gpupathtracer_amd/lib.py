@@ -21,7 +21,7 @@ EXPORTS = [
     "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
-    "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_load_obj", "ff_free_triangles",
+    "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_debug_check_ieee", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
 ]
 
@@ -83,6 +83,7 @@ def load():
     lib.ff_set_collect_stats.argtypes = [vp, i32]
     lib.ff_stats.argtypes = [vp, P(T.FfStats)]
     lib.ff_debug_counters.argtypes = [vp, P(C.c_ulonglong)]
+    lib.ff_debug_check_ieee.argtypes = [vp, P(C.c_ulonglong)]
     lib.ff_load_obj.argtypes = [C.c_char_p, P(P(T.FfTriangle)), P(i32)]
     lib.ff_free_triangles.argtypes = [P(T.FfTriangle)]
     lib.ff_free_triangles.restype = None
@@ -239,6 +240,12 @@ class Tracer:
         st = T.FfStats()
         check(self._lib.ff_stats(self._state, C.byref(st)))
         return st
+
+    def check_ieee(self):
+        """(reciprocal mismatches, square-root mismatches) of the kernels' lean IEEE sequences over all 2^32 floats."""
+        buf = (C.c_ulonglong * 2)()
+        check(self._lib.ff_debug_check_ieee(self._state, buf))
+        return int(buf[0]), int(buf[1])
 
     def debug_counters(self):
         buf = (C.c_ulonglong * 24)()

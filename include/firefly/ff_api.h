@@ -195,6 +195,10 @@ FF_API int ff_stats(FfState* state, FfStats* out);
  * tests; [16..18] wave cycles in mesh starts / inner-node phases / leaf phases. */
 FF_API int ff_debug_counters(FfState* state, unsigned long long* out24);
 
+/* Self-check of the kernels' arithmetic: their correctly rounded 1/x and sqrt(x) against the compiler's IEEE expansions on
+ * every one of the 2^32 float bit patterns; out_mismatches2[0] / [1] must come back 0 (a few milliseconds). */
+FF_API int ff_debug_check_ieee(FfState* state, unsigned long long* out_mismatches2);
+
 /* ---- mesh loading (next-row scope: LoadMesh, utilities.h:781-840) ------------------------------- */
 
 /* Reads a Wavefront OBJ with LoadMesh's semantics: one FfTriangle per face from the face's first three

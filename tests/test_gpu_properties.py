@@ -271,3 +271,9 @@ def test_c_example_through_the_abi(tracer, tmp_path):
     tracer.upload_scene(sf)
     rgb8, _ = tracer.render(sf.camera(96, 64), lib.render_params(96, 64, 3, 5))
     assert np.array_equal(img, rgb8) and img.any()
+
+
+def test_lean_ieee_sequences_are_exact_for_every_float(tracer):
+    """The kernels replace the IEEE expansions of 1/x and sqrt(x) by one Newton step on the hardware estimates inside
+    2^-60..2^60 (full expansion outside): bit-identical for all 2^32 inputs, or the parity claims would not hold."""
+    assert tracer.check_ieee() == (0, 0)
