@@ -25,6 +25,7 @@ struct FfState {
     // scene (device)
     GeomRecord* d_geoms = nullptr;
     TriRecord* d_tris = nullptr;
+    TriNormals* d_normals = nullptr; // vertex normals, parallel to d_tris
     BvhNode* d_nodes = nullptr;
     int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
     bool has_specular = false;
@@ -90,10 +91,12 @@ void free_scene(FfState* s)
 {
     if (s->d_geoms) (void)hipFree(s->d_geoms);
     if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_normals) (void)hipFree(s->d_normals);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_parent) (void)hipFree(s->d_parent);
     s->d_geoms = nullptr;
     s->d_tris = nullptr;
+    s->d_normals = nullptr;
     s->d_nodes = nullptr;
     s->d_parent = nullptr;
     s->h_geoms.clear();
@@ -124,7 +127,7 @@ int check_params(const FfRenderParams* p)
     if (p->bounces < 1 || p->bounces > 255) return fail(FF_ERR_INVALID_ARG, "bounces must be in 1..255 (got %d)", p->bounces);
     if (p->spp < 1 || p->spp >= (1 << 24)) return fail(FF_ERR_INVALID_ARG, "spp must be in 1..2^24-1 (got %d)", p->spp);
     if (p->trace_mode != FF_TRACE_BRUTE_FORCE && p->trace_mode != FF_TRACE_BVH) return fail(FF_ERR_INVALID_ARG, "unknown trace_mode %d", p->trace_mode);
-    if (p->shade_mode != FF_SHADE_NORMAL_DEBUG && p->shade_mode != FF_SHADE_DIFFUSE_PATH) return fail(FF_ERR_INVALID_ARG, "unknown shade_mode %d", p->shade_mode);
+    if (p->shade_mode != FF_SHADE_NORMAL_DEBUG && p->shade_mode != FF_SHADE_DIFFUSE_PATH && p->shade_mode != FF_SHADE_DIFFUSE_PATH_SMOOTH) return fail(FF_ERR_INVALID_ARG, "unknown shade_mode %d", p->shade_mode);
     if (p->grid_mode != FF_GRID_FULL && p->grid_mode != FF_GRID_REFERENCE_FLOOR) return fail(FF_ERR_INVALID_ARG, "unknown grid_mode %d", p->grid_mode);
     if (p->spp_per_launch < 0) return fail(FF_ERR_INVALID_ARG, "spp_per_launch must be >= 0");
     return FF_OK;
@@ -200,6 +203,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.has_specular = s->has_specular ? 1 : 0;
     k.geoms = s->d_geoms;
     k.tris = s->d_tris;
+    k.trinormals = prm->shade_mode == FF_SHADE_DIFFUSE_PATH_SMOOTH ? reinterpret_cast<const float4*>(s->d_normals) : nullptr;
     k.nodes = s->d_nodes;
     const int block_threads = prm->trace_mode == FF_TRACE_BVH ? s->block_threads : kBlockThreads;
     k.stack_depth = s->max_depth + 1; // at most one pending sibling per level above the cursor, plus one spare slot
@@ -359,8 +363,9 @@ int place_single_leaf_mesh(FfState* s, const FfTriangle* tris, int count, const 
 {
     std::vector<BvhNode> tn;
     std::vector<TriRecord> tt;
+    std::vector<TriNormals> nn;
     int depth = 0;
-    build_mesh_bvh(tris, count, bp, tn, tt, &depth);
+    build_mesh_bvh(tris, count, bp, tn, tt, &depth, &nn);
     for (BvhNode& nd : tn) {
         int* links[2] = { &nd.left, &nd.right };
         for (int* l : links) {
@@ -374,6 +379,7 @@ int place_single_leaf_mesh(FfState* s, const FfTriangle* tris, int count, const 
     }
     FF_HIP(hipMemcpy(s->d_nodes + node_base, tn.data(), tn.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     FF_HIP(hipMemcpy(s->d_tris + tri_first, tt.data(), tt.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
+    FF_HIP(hipMemcpy(s->d_normals + tri_first, nn.data(), nn.size() * sizeof(TriNormals), hipMemcpyHostToDevice));
     *out_nodes = (int)tn.size();
     *out_depth = depth;
     return FF_OK;
@@ -408,6 +414,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
         if (g.type == FF_GEOM_TRIANGLEMESH && g.tri_count > 0) node_cap += gpu_build_max_nodes(g.tri_count);
     FF_HIP(hipMalloc((void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
     FF_HIP(hipMalloc((void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
+    FF_HIP(hipMalloc((void**)&s->d_normals, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriNormals)));
     FF_HIP(hipMalloc((void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
     s->node_capacity = node_cap;
     s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
@@ -427,7 +434,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
             if (st != FF_OK) return st;
             const auto t0 = std::chrono::steady_clock::now();
             MeshBuildInfo info;
-            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, r.tri_count, r.tri_first, node_base, bp.max_leaf_tris, s->d_tris, s->d_nodes, &info);
+            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, r.tri_count, r.tri_first, node_base, bp.max_leaf_tris, s->d_tris, s->d_normals, s->d_nodes, &info);
             if (st != FF_OK) return st;
             FF_HIP(hipStreamSynchronize(s->stream));
             bs.build_ms += ms_since(t0);
@@ -493,6 +500,9 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     const size_t tri_bytes = (cs.tris.size() ? cs.tris.size() : 1) * sizeof(TriRecord);
     const size_t node_bytes = (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(BvhNode);
     FF_HIP(hipMalloc((void**)&s->d_tris, tri_bytes));
+    FF_HIP(hipMalloc((void**)&s->d_normals, tri_bytes));
+    static_assert(sizeof(TriNormals) == sizeof(TriRecord), "parallel arrays of equal stride");
+    if (!cs.normals.empty()) FF_HIP(hipMemcpy(s->d_normals, cs.normals.data(), cs.normals.size() * sizeof(TriNormals), hipMemcpyHostToDevice));
     FF_HIP(hipMalloc((void**)&s->d_nodes, node_bytes));
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
@@ -593,7 +603,7 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
             st = place_single_leaf_mesh(s, triangles, count, bp, rec.tri_first, slot.node_first, &slot.node_count, &slot.depth);
         } else {
             MeshBuildInfo info;
-            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, bp.max_leaf_tris, s->d_tris, s->d_nodes, &info);
+            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, bp.max_leaf_tris, s->d_tris, s->d_normals, s->d_nodes, &info);
             slot.node_count = info.node_count;
             slot.depth = info.depth;
         }
@@ -608,7 +618,7 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
             slot.parents_linked = true;
         }
         st = gpu_refit_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, slot.node_count, s->d_parent + slot.node_first, s->d_tris,
-                            s->d_nodes);
+                            s->d_normals, s->d_nodes);
         if (st != FF_OK) return st;
         bs.last_operation = 1;
     }

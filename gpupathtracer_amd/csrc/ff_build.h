@@ -32,11 +32,12 @@ struct MeshBuildInfo {
 inline size_t gpu_build_max_nodes(int tri_count) { return tri_count > 1 ? (size_t)tri_count - 1 : 1; }
 
 // Build the BVH of one mesh on the device.  d_src: the caller's Triangle array copied to the device (tri_count x 96 B).
-// Writes TriRecords [tri_first, tri_first + tri_count) in leaf order and inner nodes from node_base on.  Synchronises the
+// Writes TriRecords (and the parallel vertex-normal records) [tri_first, tri_first + tri_count) in leaf order and inner
+// nodes from node_base on.  Synchronises the
 // stream once (the node count of this mesh places the next one).  tri_count must exceed max_leaf (smaller meshes are a
 // single leaf and are assembled on the host).
 int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int tri_count, int tri_first, int node_base, int max_leaf,
-                   TriRecord* d_tris, BvhNode* d_nodes, MeshBuildInfo* out);
+                   TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes, MeshBuildInfo* out);
 
 // parent[n - node_first] = (parent node index << 1 | side) for every inner node n of the mesh, -1 for its root.
 int gpu_link_parents(hipStream_t stream, const BvhNode* d_nodes, int node_first, int node_count, int* d_parent);
@@ -46,6 +47,6 @@ int gpu_link_parents(hipStream_t stream, const BvhNode* d_nodes, int node_first,
 // boxes to the root.  Works on trees from either builder.  d_parent: from gpu_link_parents.  d_counters: node_count ints
 // of scratch.  Asynchronous on `stream`.
 int gpu_refit_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int tri_count, int tri_first, int node_first, int node_count,
-                   const int* d_parent, TriRecord* d_tris, BvhNode* d_nodes);
+                   const int* d_parent, TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes);
 
 } // namespace ff

@@ -290,8 +290,15 @@ __device__ __forceinline__ void write_record(TriRecord& r, const FfTriangle& t, 
     r.pad1 = 0;
 }
 
+__device__ __forceinline__ void write_normals(TriNormals& n, const FfTriangle& t)
+{
+    n.n0[0] = t.m_n0.x; n.n0[1] = t.m_n0.y; n.n0[2] = t.m_n0.z; n.pad0 = 0.f;
+    n.n1[0] = t.m_n1.x; n.n1[1] = t.m_n1.y; n.n1[2] = t.m_n1.z; n.pad1 = 0.f;
+    n.n2[0] = t.m_n2.x; n.n2[1] = t.m_n2.y; n.n2[2] = t.m_n2.z; n.pad2 = 0.f;
+}
+
 __global__ __launch_bounds__(kBuildBlock) void records_kernel(const FfTriangle* __restrict__ src, const uint32_t* __restrict__ vals, int T, int tri_first,
-                                                               TriRecord* __restrict__ tris)
+                                                               TriRecord* __restrict__ tris, TriNormals* __restrict__ normals)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= T) return;
@@ -299,11 +306,15 @@ __global__ __launch_bounds__(kBuildBlock) void records_kernel(const FfTriangle* 
     TriRecord r;
     write_record(r, src[orig], orig);
     tris[tri_first + j] = r;
+    TriNormals n;
+    write_normals(n, src[orig]);
+    normals[tri_first + j] = n;
 }
 
 // ---- refit ------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kBuildBlock) void refresh_records_kernel(const FfTriangle* __restrict__ src, int T, int tri_first, TriRecord* __restrict__ tris)
+__global__ __launch_bounds__(kBuildBlock) void refresh_records_kernel(const FfTriangle* __restrict__ src, int T, int tri_first, TriRecord* __restrict__ tris,
+                                                                       TriNormals* __restrict__ normals)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= T) return;
@@ -312,6 +323,9 @@ __global__ __launch_bounds__(kBuildBlock) void refresh_records_kernel(const FfTr
     TriRecord r;
     write_record(r, src[orig], orig);
     tris[tri_first + j] = r;
+    TriNormals n;
+    write_normals(n, src[orig]);
+    normals[tri_first + j] = n;
 }
 
 __global__ __launch_bounds__(kBuildBlock) void link_parents_kernel(const BvhNode* __restrict__ nodes, int node_first, int node_count, int* __restrict__ parent)
@@ -462,7 +476,7 @@ void free_build_scratch(BuildScratch& s)
 }
 
 int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int T, int tri_first, int node_base, int max_leaf,
-                   TriRecord* d_tris, BvhNode* d_nodes, MeshBuildInfo* out)
+                   TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes, MeshBuildInfo* out)
 {
     if (T <= max_leaf || T < 2) return fail(FF_ERR_INVALID_ARG, "gpu_build_mesh: %d triangles fit one leaf", T);
     if (max_leaf < 1 || max_leaf > 8) return fail(FF_ERR_INVALID_ARG, "max_leaf_tris must be 1..8");
@@ -501,7 +515,7 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
     rank_scatter_kernel<<<grid_for(emitted), kBuildBlock, 0, stream>>>(emitted, b.ids_out, b.new_index);
     emit_kernel<<<grid_for(emitted), kBuildBlock, 0, stream>>>(T, emitted, max_leaf, tri_first, node_base, b.bounds, b.ids_out, b.new_index, b.left, b.right,
                                                                b.first, b.last, b.boxes, d_nodes);
-    records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, tri_first, d_tris);
+    records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, tri_first, d_tris, d_normals);
     FFB_HIP(hipGetLastError());
     out->root = node_base;
     out->node_count = emitted;
@@ -519,7 +533,7 @@ int gpu_link_parents(hipStream_t stream, const BvhNode* d_nodes, int node_first,
 }
 
 int gpu_refit_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int T, int tri_first, int node_first, int node_count,
-                   const int* d_parent, TriRecord* d_tris, BvhNode* d_nodes)
+                   const int* d_parent, TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes)
 {
     if (T <= 0 || node_count <= 0) return FF_OK;
     Carver probe(nullptr);
@@ -534,7 +548,7 @@ int gpu_refit_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
     FFB_HIP(hipMemsetAsync(arrivals, 0, (size_t)node_count * sizeof(int), stream));
     const int tri_grid = grid_for(T);
     bounds_kernel<<<tri_grid < 1024 ? tri_grid : 1024, kBuildBlock, 0, stream>>>(d_src, T, bounds);
-    refresh_records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, T, tri_first, d_tris);
+    refresh_records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, T, tri_first, d_tris, d_normals);
     refit_kernel<<<grid_for(node_count), kBuildBlock, 0, stream>>>(d_src, d_tris, bounds, node_first, node_count, d_parent, d_nodes, arrivals);
     FFB_HIP(hipGetLastError());
     return FF_OK;

@@ -30,6 +30,15 @@ struct TriRecord {
 };
 static_assert(sizeof(TriRecord) == 48, "48-byte triangle record");
 
+// The vertex normals a Triangle carries (utilities.h:163-170), same order as the TriRecords; read only when a hit is
+// shaded with FF_SHADE_DIFFUSE_PATH_SMOOTH.
+struct TriNormals {
+    float n0[3], pad0;
+    float n1[3], pad1;
+    float n2[3], pad2;
+};
+static_assert(sizeof(TriNormals) == 48, "48-byte vertex-normal record");
+
 // One 64-byte inner BVH node: both child boxes (object space, conservatively padded) and both child links.
 // link >= 0: index of an inner node (global node array).  link < 0: leaf, ~link = (first_tri << 3) | (count - 1),
 // first_tri indexing the global TriRecord array.  A mesh that fits one leaf has both links on that leaf.
@@ -71,6 +80,7 @@ static_assert(sizeof(GeomRecord) == 16 * 16 + 32, "GeomRecord layout");
 struct CompiledScene {
     std::vector<GeomRecord> geoms;
     std::vector<TriRecord> tris;   // leaf order
+    std::vector<TriNormals> normals; // parallel to tris
     std::vector<BvhNode> nodes;    // all meshes, each mesh's nodes contiguous in breadth-first order
     int max_depth = 0;             // deepest root-to-leaf path in inner nodes over all meshes
     uint64_t total_tris = 0;
@@ -89,7 +99,7 @@ BvhBuildParams default_bvh_params();
 // Build the object-space BVH of one mesh.  Appends inner nodes to `nodes` (breadth-first, root first) and the mesh's
 // triangles, in leaf order, to `tris`.  Returns the root inner-node index (into `nodes`) and the tree depth.
 int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams& params, std::vector<BvhNode>& nodes,
-                   std::vector<TriRecord>& tris, int* out_depth);
+                   std::vector<TriRecord>& tris, int* out_depth, std::vector<TriNormals>* normals = nullptr);
 
 // Flatten host geometries into device records.  Returns an FfStatus.  build_bvh = false fills the geometry records only
 // (tri_first / tri_count assigned, bvh_root = -1, no triangle records, no nodes): the device builder's input.

@@ -48,6 +48,7 @@ struct KParams {
     int has_specular; // some surface is MIRROR or GLASS
     const GeomRecord* geoms;
     const TriRecord* tris;
+    const float4* trinormals; // vertex normals (3 float4 per triangle, parallel to tris); null unless FF_SHADE_DIFFUSE_PATH_SMOOTH
     const BvhNode* nodes;
     int lds_nodes;   // nodes [0, lds_nodes) are staged in LDS
     int stack_depth; // entries per lane in the LDS traversal stack

@@ -196,6 +196,33 @@ __device__ __forceinline__ float triangle_t(const float4 A, const float4 E1, con
     return t > kTriEpsilon ? t : -1.0f; // :97
 }
 
+// The barycentrics of kernel.cu:62,70,80-81 (u = dot(tvec, pvec) * invDet, v = dot(d, qvec) * invDet) for a triangle the
+// ray is known to hit, and the vertex normals interpolated with them: n = ((1 - u) - v) n0 + u n1 + v n2.  A triangle whose
+// three vertex normals are zero (an OBJ without vn) keeps its geometric normal: returns false.
+__device__ __forceinline__ bool smooth_normal(const float4 A, const float4 E1, const float4 E2, const float4* __restrict__ nrm, const Ray& r, float& nx,
+                                              float& ny, float& nz)
+{
+    const float px = r.dy * E2.z - E2.y * r.dz, py = r.dz * E2.x - E2.z * r.dx, pz = r.dx * E2.y - E2.x * r.dy;
+    const float det = dot3(E1.x, E1.y, E1.z, px, py, pz);
+    const float tx = r.ox - A.x, ty = r.oy - A.y, tz = r.oz - A.z;
+    float u = dot3(tx, ty, tz, px, py, pz);
+    const float qx = ty * E1.z - E1.y * tz, qy = tz * E1.x - E1.z * tx, qz = tx * E1.y - E1.x * ty;
+    float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz);
+    const float invDet = ieee_rcp(det);
+    u = u * invDet;
+    v = v * invDet;
+    const float4 n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
+    const float w = (1.0f - u) - v;
+    const float sx = (w * n0.x + u * n1.x) + v * n2.x;
+    const float sy = (w * n0.y + u * n1.y) + v * n2.y;
+    const float sz = (w * n0.z + u * n1.z) + v * n2.z;
+    if (sx == 0.0f && sy == 0.0f && sz == 0.0f) return false;
+    nx = sx;
+    ny = sy;
+    nz = sz;
+    return true;
+}
+
 // kernel.cu:8-32 for an object-space ray and plane normal n.  Returns t or -1.
 __device__ __forceinline__ float plane_t(float nx, float ny, float nz, const Ray& r)
 {
@@ -245,6 +272,18 @@ __device__ __forceinline__ void fill_sphere_normal(const GeomRecord* __restrict_
     sphere_normal(G.plane_n[3], osr, t, best.cx, best.cy, best.cz);
 }
 
+// Brute-force path: the interpolated vertex normal of a finished triangle hit (FF_SHADE_DIFFUSE_PATH_SMOOTH).
+__device__ __forceinline__ void fill_smooth_normal(const GeomRecord* __restrict__ geoms, const TriRecord* __restrict__ tris,
+                                                   const float4* __restrict__ trinormals, const Ray& wr, Best& best)
+{
+    if (!trinormals || best.geom < 0 || best.rec < 0) return;
+    Ray osr;
+    float len;
+    object_space_ray(geoms[best.geom], wr, osr, len);
+    const float4* tp = reinterpret_cast<const float4*>(tris) + (size_t)best.rec * 3;
+    smooth_normal(tp[0], tp[1], tp[2], trinormals + (size_t)best.rec * 3, osr, best.cx, best.cy, best.cz);
+}
+
 // ---- LDS layout of the BVH kernels -----------------------------------------------------------------------------------
 //
 //   [ nodes: 4 planes of lds_nodes x 16 B ][ traversal stacks: stack_depth x BLOCK x 4 B, lane-strided ][ geometry records: G x 288 B ]
@@ -261,12 +300,14 @@ struct Lds {
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
+    const float4* smooth_normals; // non-null: triangle hits carry the interpolated vertex normal (FF_SHADE_DIFFUSE_PATH_SMOOTH)
 };
 
-__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid, int num_quads)
+__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr)
 {
     Lds L;
     L.num_quads = num_quads;
+    L.smooth_normals = smooth_normals;
     L.node_count = lds_nodes;
     L.stride = block;
     L.stack_base = lds_nodes * 16 + tid;
@@ -442,6 +483,7 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
         H.cx = e1y * e2z - e2y * e1z; // kernel.cu:101 cross(edge1, edge2), shading normalises it where the reference does
         H.cy = e1z * e2x - e2z * e1x;
         H.cz = e1x * e2y - e2x * e1y;
+        if (L.smooth_normals) smooth_normal(a, b, c, L.smooth_normals + (size_t)rec * 3, osr, H.cx, H.cy, H.cz);
     } else {
         const float4 pn = lds_geom4(L, g, 11);
         if (g >= L.num_quads) {
@@ -824,7 +866,8 @@ __device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRec
 // Must be called by every thread of the workgroup (it contains barriers); `live` masks lanes without a ray.
 template <bool STATS>
 __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__ geoms, int num_geoms, const TriRecord* __restrict__ tris,
-                                                  float4* batch, bool live, const Ray& wr, Best& best, Counters& cnt)
+                                                  float4* batch, bool live, const Ray& wr, Best& best, Counters& cnt,
+                                                  const float4* __restrict__ trinormals = nullptr)
 {
     best.dist = kInf;
     best.geom = -1;
@@ -862,6 +905,7 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
     if (live) {
         fill_object_normal(geoms, tris, best);
         fill_sphere_normal(geoms, wr, best);
+        fill_smooth_normal(geoms, tris, trinormals, wr, best);
         cnt.rays += 1;
     }
 }
@@ -1245,7 +1289,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1357,7 +1401,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, p.num_quads);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, p.num_quads, p.trinormals);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
     const int P = p.pool_slots;
@@ -1524,7 +1568,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
         // every thread of the workgroup takes part in staging the triangle batches
         if (__syncthreads_or(active ? 1 : 0) == 0) break;
         Best best;
-        closest_hit_brute<STATS>(p.geoms, p.num_geoms, p.tris, batch, active, P.ray, best, cnt);
+        closest_hit_brute<STATS>(p.geoms, p.num_geoms, p.tris, batch, active, P.ray, best, cnt, p.trinormals);
         if (!active) continue;
         const bool hit = best.geom >= 0;
         MaterialRef M;
@@ -1735,7 +1779,7 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
             return hipGetLastError();
         }
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
-        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0; // any build-defined extra: the full kernel
+        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr; // any build-defined extra: the full kernel
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
         if (collect_stats) {                                                                                              \

@@ -209,7 +209,7 @@ BvhBuildParams default_bvh_params()
 }
 
 int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams& params, std::vector<BvhNode>& nodes,
-                   std::vector<TriRecord>& tris, int* out_depth)
+                   std::vector<TriRecord>& tris, int* out_depth, std::vector<TriNormals>* normals)
 {
     if (count <= 0) {
         if (out_depth) *out_depth = 0;
@@ -245,6 +245,14 @@ int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams&
         r.cull_margin = std::nextafter((float)(32.0 * 5.9604644775390625e-8 * m), 3.0e38f);
         r.orig_index = B.perm[i];
         tris.push_back(r);
+        if (normals) {
+            TriNormals nr;
+            std::memset(&nr, 0, sizeof nr);
+            std::memcpy(nr.n0, &t.m_n0, 12);
+            std::memcpy(nr.n1, &t.m_n1, 12);
+            std::memcpy(nr.n2, &t.m_n2, 12);
+            normals->push_back(nr);
+        }
     }
 
     // Breadth-first numbering of inner nodes; a mesh that fits one leaf still gets an inner root with an empty right child.
@@ -401,7 +409,7 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
             r.tri_count = cnt;
             if (build_bvh) {
                 int depth = 0;
-                r.bvh_root = build_mesh_bvh(g.m_triangles, cnt, params, out.nodes, out.tris, &depth);
+                r.bvh_root = build_mesh_bvh(g.m_triangles, cnt, params, out.nodes, out.tris, &depth, &out.normals);
                 out.max_depth = std::max(out.max_depth, depth);
             }
             out.total_tris += (uint64_t)cnt;

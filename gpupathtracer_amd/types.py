@@ -148,7 +148,7 @@ assert C.sizeof(FfCamera) == 108
 BXDF_EMITTER, BXDF_DIFFUSE, BXDF_MIRROR, BXDF_GLASS, BXDF_COUNT = range(5)
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLEMESH = range(3)
 TRACE_BRUTE_FORCE, TRACE_BVH = 0, 1
-SHADE_NORMAL_DEBUG, SHADE_DIFFUSE_PATH = 0, 1
+SHADE_NORMAL_DEBUG, SHADE_DIFFUSE_PATH, SHADE_DIFFUSE_PATH_SMOOTH = 0, 1, 2
 GRID_FULL, GRID_REFERENCE_FLOOR = 0, 1
 
 # status codes (ff_api.h)

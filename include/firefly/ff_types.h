@@ -134,7 +134,9 @@ typedef enum FfTraceMode {
 
 typedef enum FfShadeMode {
     FF_SHADE_NORMAL_DEBUG = 0, /* kernel.cu:178-184: colour = abs(world normal); bounces/spp forced to 1 */
-    FF_SHADE_DIFFUSE_PATH = 1  /* N-bounce integrator with the dormant BXDF semantics, utilities.h:90-138 */
+    FF_SHADE_DIFFUSE_PATH = 1, /* N-bounce integrator with the dormant BXDF semantics, utilities.h:90-138 */
+    FF_SHADE_DIFFUSE_PATH_SMOOTH = 2 /* the same, shading triangles with the interpolated vertex normals Triangle carries
+                                      * (utilities.h:163-170) through the barycentrics of kernel.cu:80-81 */
 } FfShadeMode;
 
 typedef enum FfGridMode {

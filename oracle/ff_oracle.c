@@ -711,6 +711,30 @@ static void shade_pixel(const FfGeometry* geoms, int n, const FfCamera* cam, con
                 float e1[3] = { tr->m_v1.x - tr->m_v0.x, tr->m_v1.y - tr->m_v0.y, tr->m_v1.z - tr->m_v0.z };
                 float e2[3] = { tr->m_v2.x - tr->m_v0.x, tr->m_v2.y - tr->m_v0.y, tr->m_v2.z - tr->m_v0.z };
                 orc_cross3(e1, e2, nobj);
+                if (p->shade_mode == FF_SHADE_DIFFUSE_PATH_SMOOTH) {
+                    /* Interpolated vertex normals (U:163-170) with the barycentrics the reference computes and drops
+                     * (K:62, K:70, K:80-81): n = ((1 - u) - v) n0 + u n1 + v n2.  All-zero vertex normals (an OBJ
+                     * without vn) keep the geometric normal. */
+                    FfRay osr;
+                    object_space_ray(hg, &ray, &osr);
+                    const float* o = &osr.m_origin.x;
+                    const float* d = &osr.m_direction.x;
+                    float pvec[3], qvec[3];
+                    orc_cross3(d, e2, pvec);
+                    const float det = orc_dot3(e1, pvec);
+                    const float tvec[3] = { o[0] - tr->m_v0.x, o[1] - tr->m_v0.y, o[2] - tr->m_v0.z };
+                    float u = orc_dot3(tvec, pvec);
+                    orc_cross3(tvec, e1, qvec);
+                    float v = orc_dot3(d, qvec);
+                    const float invDet = (float)(1.0 / (double)det);
+                    u = u * invDet;
+                    v = v * invDet;
+                    const float w = (1.0f - u) - v;
+                    const float sn[3] = { (w * tr->m_n0.x + u * tr->m_n1.x) + v * tr->m_n2.x,
+                                          (w * tr->m_n0.y + u * tr->m_n1.y) + v * tr->m_n2.y,
+                                          (w * tr->m_n0.z + u * tr->m_n1.z) + v * tr->m_n2.z };
+                    if (!(sn[0] == 0.0f && sn[1] == 0.0f && sn[2] == 0.0f)) { nobj[0] = sn[0]; nobj[1] = sn[1]; nobj[2] = sn[2]; }
+                }
             } else if (hg->m_geometryType == FF_GEOM_SPHERE) {
                 /* the object-space unit normal of the hit: intersect the winning sphere again (same arithmetic, same result) */
                 FfRay osr;

@@ -14,8 +14,8 @@ def _dbg(w, h, grid=T.GRID_FULL):
     return lib.render_params(w, h, 1, 1, 1234, T.TRACE_BVH, T.SHADE_NORMAL_DEBUG, grid, 0)
 
 
-def _path(w, h, bounces, spp, seed=1234):
-    return lib.render_params(w, h, bounces, spp, seed, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+def _path(w, h, bounces, spp, seed=1234, shade=T.SHADE_DIFFUSE_PATH):
+    return lib.render_params(w, h, bounces, spp, seed, T.TRACE_BVH, shade, T.GRID_FULL, 0)
 
 
 # name -> (scene builder, pose, params builder)
@@ -44,6 +44,9 @@ CASES = {
     "dbg_spheres_96x72": (scenes.cornell_spheres_scene, "inside", lambda: _dbg(96, 72)),
     # BXDFTyp::GLASS (build-defined): glass sphere (enter, leave, total internal reflection), glass pane, mirror sphere
     "path_glass_80x60_b8_s4": (scenes.cornell_glass_scene, "inside", lambda: _path(80, 60, 8, 4, seed=31)),
+    # interpolated vertex normals (build-defined use of utilities.h:163-170 and the barycentrics of kernel.cu:80-81)
+    "smooth_cornell_96x64_b4_s4": (scenes.cornell_wahoo_scene, "inside", lambda: _path(96, 64, 4, 4, seed=9, shade=T.SHADE_DIFFUSE_PATH_SMOOTH)),
+    "smooth_blooper_64x64_b3_s3": (scenes.blooper_scene, "oblique", lambda: _path(64, 64, 3, 3, shade=T.SHADE_DIFFUSE_PATH_SMOOTH)),
 }
 
 

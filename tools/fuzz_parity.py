@@ -67,7 +67,8 @@ def rand_params(rng, w, h, mode):
     bounces, spp, seed = int(rng.integers(1, 9)), int(rng.integers(1, 5)), int(rng.integers(0, 1 << 30))
     if rng.random() < 0.2:
         return lib.render_params(w, h, 1, 1, seed, mode, T.SHADE_NORMAL_DEBUG, T.GRID_FULL, 0)
-    return lib.render_params(w, h, bounces, spp, seed, mode, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+    shade = T.SHADE_DIFFUSE_PATH_SMOOTH if rng.random() < 0.3 else T.SHADE_DIFFUSE_PATH
+    return lib.render_params(w, h, bounces, spp, seed, mode, shade, T.GRID_FULL, 0)
 
 
 def run(cases, seed, verbose=True):
