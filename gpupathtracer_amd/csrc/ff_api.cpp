@@ -358,6 +358,14 @@ int stage_triangles(FfState* s, const FfTriangle* tris, int count, double* copy_
     return FF_OK;
 }
 
+// Leaf size of the device builders: subtrees of up to this many triangles collapse into one leaf (FF_GPU_LEAF overrides).
+int device_leaf_tris(const BvhBuildParams& bp)
+{
+    int v = bp.device_leaf_tris;
+    if (const char* e = std::getenv("FF_GPU_LEAF")) v = std::atoi(e);
+    return std::max(1, std::min(bp.max_leaf_tris, v));
+}
+
 // A mesh that fits one leaf: the host builder's single node, re-based into the device arrays.
 int place_single_leaf_mesh(FfState* s, const FfTriangle* tris, int count, const BvhBuildParams& bp, int tri_first, int node_base, int* out_nodes, int* out_depth)
 {
@@ -409,6 +417,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     if (st != FF_OK) return st;
     FF_HIP(hipSetDevice(s->device));
     free_scene(s);
+    const int device_leaf = device_leaf_tris(bp);
     size_t node_cap = 0;
     for (const GeomRecord& g : cs.geoms)
         if (g.type == FF_GEOM_TRIANGLEMESH && g.tri_count > 0) node_cap += gpu_build_max_nodes(g.tri_count);
@@ -426,7 +435,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
         FfState::MeshSlot& slot = s->slots[gi];
         slot.node_first = node_base;
         slot.node_capacity = (int)gpu_build_max_nodes(r.tri_count);
-        if (r.tri_count <= bp.max_leaf_tris) {
+        if (r.tri_count <= device_leaf) {
             st = place_single_leaf_mesh(s, src, r.tri_count, bp, r.tri_first, node_base, &slot.node_count, &slot.depth);
             if (st != FF_OK) return st;
         } else {
@@ -434,7 +443,8 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
             if (st != FF_OK) return st;
             const auto t0 = std::chrono::steady_clock::now();
             MeshBuildInfo info;
-            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, r.tri_count, r.tri_first, node_base, bp.max_leaf_tris, s->d_tris, s->d_normals, s->d_nodes, &info);
+            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, r.tri_count, r.tri_first, node_base, device_leaf, s->d_tris, s->d_normals, s->d_nodes, &info,
+                                s->builder == FF_BUILD_GPU_PLOC);
             if (st != FF_OK) return st;
             FF_HIP(hipStreamSynchronize(s->stream));
             bs.build_ms += ms_since(t0);
@@ -455,7 +465,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     s->has_specular = false;
     for (const GeomRecord& g : cs.geoms) s->has_specular = s->has_specular || g.bxdf_type == FF_BXDF_MIRROR || g.bxdf_type == FF_BXDF_GLASS;
     s->num_tris = cs.total_tris;
-    s->scene_builder = FF_BUILD_GPU_LBVH;
+    s->scene_builder = s->builder;
     refresh_scene_extent(s);
     s->has_scene = true;
     return FF_OK;
@@ -467,7 +477,7 @@ int ff_set_builder(FfState* s, int builder)
 {
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_set_builder: state is null");
-    if (builder != FF_BUILD_HOST_SAH && builder != FF_BUILD_GPU_LBVH) return fail(FF_ERR_INVALID_ARG, "ff_set_builder: unknown builder %d", builder);
+    if (builder != FF_BUILD_HOST_SAH && builder != FF_BUILD_GPU_LBVH && builder != FF_BUILD_GPU_PLOC) return fail(FF_ERR_INVALID_ARG, "ff_set_builder: unknown builder %d", builder);
     s->builder = builder;
     return FF_OK;
 }
@@ -479,7 +489,7 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     const auto t_call = std::chrono::steady_clock::now();
     s->build_stats = FfBuildStats();
     const BvhBuildParams bp = default_bvh_params();
-    if (s->builder == FF_BUILD_GPU_LBVH) {
+    if (s->builder != FF_BUILD_HOST_SAH) {
         const int st = upload_with_device_builder(s, host_geometries, n, bp);
         s->build_stats.total_ms = ms_since(t_call);
         if (st != FF_OK) free_scene(s);
@@ -587,8 +597,8 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
     if (gi < 0 || s->h_geoms[gi].type != FF_GEOM_TRIANGLEMESH) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: geometry %d is not an uploaded mesh", geometry_index);
     GeomRecord& rec = s->h_geoms[gi];
     if (count != rec.tri_count || count <= 0) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: %d triangles, the uploaded mesh has %d", count, rec.tri_count);
-    if (mode == FF_UPDATE_REBUILD && s->scene_builder != FF_BUILD_GPU_LBVH)
-        return fail(FF_ERR_UNSUPPORTED, "ff_update_mesh: rebuilding in place needs a scene uploaded with FF_BUILD_GPU_LBVH (host-built trees are packed)");
+    if (mode == FF_UPDATE_REBUILD && s->scene_builder == FF_BUILD_HOST_SAH)
+        return fail(FF_ERR_UNSUPPORTED, "ff_update_mesh: rebuilding in place needs a scene uploaded with a device builder (host-built trees are packed)");
     const auto t_call = std::chrono::steady_clock::now();
     FfBuildStats& bs = s->build_stats;
     bs.copy_ms = bs.build_ms = 0.0;
@@ -599,11 +609,12 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
     if (st != FF_OK) return st;
     const auto t_build = std::chrono::steady_clock::now();
     if (mode == FF_UPDATE_REBUILD) {
-        if (count <= bp.max_leaf_tris) {
+        if (count <= device_leaf_tris(bp)) {
             st = place_single_leaf_mesh(s, triangles, count, bp, rec.tri_first, slot.node_first, &slot.node_count, &slot.depth);
         } else {
             MeshBuildInfo info;
-            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, bp.max_leaf_tris, s->d_tris, s->d_normals, s->d_nodes, &info);
+            st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, device_leaf_tris(bp), s->d_tris, s->d_normals, s->d_nodes, &info,
+                                s->scene_builder == FF_BUILD_GPU_PLOC);
             slot.node_count = info.node_count;
             slot.depth = info.depth;
         }

@@ -35,9 +35,10 @@ inline size_t gpu_build_max_nodes(int tri_count) { return tri_count > 1 ? (size_
 // Writes TriRecords (and the parallel vertex-normal records) [tri_first, tri_first + tri_count) in leaf order and inner
 // nodes from node_base on.  Synchronises the
 // stream once (the node count of this mesh places the next one).  tri_count must exceed max_leaf (smaller meshes are a
-// single leaf and are assembled on the host).
+// single leaf and are assembled on the host).  ploc = false: LBVH (Karras hierarchy on the Morton order); true: PLOC
+// (agglomerative clustering on the Morton order: slower to build, close to SAH quality).
 int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int tri_count, int tri_first, int node_base, int max_leaf,
-                   TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes, MeshBuildInfo* out);
+                   TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes, MeshBuildInfo* out, bool ploc = false);
 
 // parent[n - node_first] = (parent node index << 1 | side) for every inner node n of the mesh, -1 for its root.
 int gpu_link_parents(hipStream_t stream, const BvhNode* d_nodes, int node_first, int node_count, int* d_parent);

@@ -208,6 +208,145 @@ __global__ __launch_bounds__(kBuildBlock) void fit_kernel(const FfTriangle* __re
     }
 }
 
+// ---- PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) --------------------------------------------------
+//
+// Bottom-up agglomeration on the Morton-sorted leaves: every cluster finds, within a window of +-kPlocRadius positions,
+// the neighbour whose union with it has the smallest surface area; mutual choices merge into a new node; the survivors
+// are compacted in order and the loop repeats until one cluster is left.  Trees are close to SAH quality, unlike the
+// LBVH's midpoint splits.  Internal node ids are handed out from T-2 downwards so that the last merge - the root - is
+// node 0, which is what the ranking / emission stages expect.
+
+constexpr int kPlocRadius = 16;
+
+__global__ __launch_bounds__(kBuildBlock) void leaf_boxes_kernel(const FfTriangle* __restrict__ src, const uint32_t* __restrict__ vals, int T,
+                                                                  float* __restrict__ boxes, int* __restrict__ clusters)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const FfTriangle& t = src[vals[j]];
+    Box6 b = empty_box();
+    grow(b, t.m_v0);
+    grow(b, t.m_v1);
+    grow(b, t.m_v2);
+    float* mine = boxes + (size_t)((T - 1) + j) * 6;
+    for (int k = 0; k < 3; ++k) { mine[k] = b.mn[k]; mine[3 + k] = b.mx[k]; }
+    clusters[j] = ~j;
+}
+
+__device__ __forceinline__ float union_area(const float* a, const float* b)
+{
+    const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]);
+    const float dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]);
+    const float dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void ploc_neighbour_kernel(int n, int T, const int* __restrict__ clusters, const float* __restrict__ boxes,
+                                                                      int* __restrict__ nearest)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float mine[6];
+    const float* mb = boxes + (size_t)box_slot(clusters[i], T) * 6;
+    for (int k = 0; k < 6; ++k) mine[k] = mb[k];
+    float best = __builtin_huge_valf();
+    int best_j = -1;
+    // Candidates are visited from the closest position outwards and only a strictly smaller area replaces the choice, so
+    // among equal areas (regular tessellations are full of them) the closest position wins; at equal distance an even
+    // position looks right first and an odd one left first, which makes (2k, 2k+1) choose each other.
+    for (int d = 1; d <= kPlocRadius; ++d) {
+        const int first_j = (i & 1) ? i - d : i + d, second_j = (i & 1) ? i + d : i - d;
+        const int cand[2] = { first_j, second_j };
+        for (int c = 0; c < 2; ++c) {
+            const int j = cand[c];
+            if (j < 0 || j >= n) continue;
+            const float a = union_area(mine, boxes + (size_t)box_slot(clusters[j], T) * 6);
+            if (a < best) {
+                best = a;
+                best_j = j;
+            }
+        }
+    }
+    nearest[i] = best_j;
+}
+
+// Mutual nearest neighbours merge (the lower position creates the node); everything else survives unchanged.
+__global__ __launch_bounds__(kBuildBlock) void ploc_merge_kernel(int n, int T, const int* __restrict__ clusters, const int* __restrict__ nearest,
+                                                                  float* __restrict__ boxes, int* __restrict__ left, int* __restrict__ right,
+                                                                  int* __restrict__ node_parent, int* __restrict__ leaf_parent, int* __restrict__ sizes,
+                                                                  int* counters /* [2] nodes created */, int* __restrict__ merged, uint32_t* __restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = nearest[i];
+    const bool mutual = j >= 0 && nearest[j] == i;
+    if (!mutual) {
+        merged[i] = clusters[i];
+        keep[i] = 1u;
+        return;
+    }
+    if (i > j) {
+        keep[i] = 0u;
+        return;
+    }
+    const int a = clusters[i], b = clusters[j];
+    const int id = (T - 2) - atomicAdd(&counters[2], 1);
+    if (id == 0) node_parent[0] = -1; // the last merge is the root
+    left[id] = a;
+    right[id] = b;
+    if (a >= 0) node_parent[a] = id; else leaf_parent[~a] = id;
+    if (b >= 0) node_parent[b] = id; else leaf_parent[~b] = id;
+    sizes[id] = (a >= 0 ? sizes[a] : 1) + (b >= 0 ? sizes[b] : 1);
+    const float* ba = boxes + (size_t)box_slot(a, T) * 6;
+    const float* bb = boxes + (size_t)box_slot(b, T) * 6;
+    float* nb = boxes + (size_t)id * 6;
+    for (int k = 0; k < 3; ++k) {
+        nb[k] = fminf(ba[k], bb[k]);
+        nb[3 + k] = fmaxf(ba[3 + k], bb[3 + k]);
+    }
+    merged[i] = id;
+    keep[i] = 1u;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void ploc_compact_kernel(int n, const int* __restrict__ merged, const uint32_t* __restrict__ keep,
+                                                                    const uint32_t* __restrict__ position, int* __restrict__ clusters_out, int* counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (keep[i]) clusters_out[position[i]] = merged[i];
+    if (i == n - 1) counters[3] = (int)(position[i] + keep[i]); // clusters left
+}
+
+// Depth-first position of every node's first leaf: the sum, over the ancestors it reaches as a RIGHT child, of the left
+// sibling's size.  Gives every internal node its contiguous triangle range and every leaf its place in the leaf order.
+__global__ __launch_bounds__(kBuildBlock) void ploc_ranges_kernel(int T, const int* __restrict__ left, const int* __restrict__ right,
+                                                                   const int* __restrict__ node_parent, const int* __restrict__ leaf_parent,
+                                                                   const int* __restrict__ sizes, int* __restrict__ first, int* __restrict__ last,
+                                                                   int* __restrict__ leaf_position)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x; // [0, T-1): internal nodes, [T-1, 2T-1): leaves
+    if (x >= 2 * T - 1) return;
+    const bool is_leaf = x >= T - 1;
+    int ref = is_leaf ? ~(x - (T - 1)) : x;
+    int parent = is_leaf ? leaf_parent[x - (T - 1)] : node_parent[x];
+    if (!is_leaf && x == 0) parent = -1;
+    int offset = 0;
+    for (int guard = 0; parent >= 0 && guard < 4096; ++guard) {
+        if (right[parent] == ref) {
+            const int l = left[parent];
+            offset += l >= 0 ? sizes[l] : 1;
+        }
+        ref = parent;
+        parent = parent == 0 ? -1 : node_parent[parent];
+    }
+    if (is_leaf) {
+        leaf_position[x - (T - 1)] = offset;
+    } else {
+        first[x] = offset;
+        last[x] = offset + sizes[x] - 1;
+    }
+}
+
 // Depth key of every internal node: its depth (root = 1) if it becomes a traversal node, kNotEmitted otherwise.
 __global__ __launch_bounds__(kBuildBlock) void rank_key_kernel(int T, int max_leaf, const int* __restrict__ first, const int* __restrict__ last,
                                                                 const int* __restrict__ node_parent, uint32_t* __restrict__ depth_key,
@@ -244,7 +383,8 @@ __device__ __forceinline__ float mesh_pad(const int* bounds)
 __global__ __launch_bounds__(kBuildBlock) void emit_kernel(int T, int emitted, int max_leaf, int tri_first, int node_base, const int* __restrict__ bounds,
                                                             const uint32_t* __restrict__ sorted_ids, const int* __restrict__ new_index,
                                                             const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
-                                                            const int* __restrict__ last, const float* __restrict__ boxes, BvhNode* __restrict__ nodes)
+                                                            const int* __restrict__ last, const float* __restrict__ boxes, const int* __restrict__ leaf_position,
+                                                            BvhNode* __restrict__ nodes)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= emitted) return;
@@ -265,7 +405,7 @@ __global__ __launch_bounds__(kBuildBlock) void emit_kernel(int T, int emitted, i
             mx[k] = b[3 + k] + pad;
         }
         if (c < 0) {
-            link[side] = ~(((tri_first + ~c) << 3) | 0);
+            link[side] = ~(((tri_first + (leaf_position ? leaf_position[~c] : ~c)) << 3) | 0);
         } else {
             const int len = last[c] - first[c] + 1;
             link[side] = len <= max_leaf ? ~(((tri_first + first[c]) << 3) | (len - 1)) : node_base + new_index[c];
@@ -298,17 +438,19 @@ __device__ __forceinline__ void write_normals(TriNormals& n, const FfTriangle& t
 }
 
 __global__ __launch_bounds__(kBuildBlock) void records_kernel(const FfTriangle* __restrict__ src, const uint32_t* __restrict__ vals, int T, int tri_first,
-                                                               TriRecord* __restrict__ tris, TriNormals* __restrict__ normals)
+                                                               const int* __restrict__ leaf_position, TriRecord* __restrict__ tris,
+                                                               TriNormals* __restrict__ normals)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= T) return;
     const int orig = (int)vals[j];
+    const int dst = tri_first + (leaf_position ? leaf_position[j] : j);
     TriRecord r;
     write_record(r, src[orig], orig);
-    tris[tri_first + j] = r;
+    tris[dst] = r;
     TriNormals n;
     write_normals(n, src[orig]);
-    normals[tri_first + j] = n;
+    normals[dst] = n;
 }
 
 // ---- refit ------------------------------------------------------------------------------------------------------------
@@ -431,6 +573,8 @@ struct BuildBuffers {
     int *left, *right, *first, *last, *node_parent, *leaf_parent, *arrivals, *new_index;
     float* boxes;
     uint32_t *depth_in, *depth_out, *ids_in, *ids_out;
+    int *clusters_a, *clusters_b, *nearest, *merged, *sizes, *leaf_position; // PLOC
+    uint32_t *keep, *position;
     void* sort_temp;
     size_t sort_temp_bytes;
     size_t total;
@@ -460,6 +604,14 @@ BuildBuffers carve_build(void* base, int T, size_t sort_temp_bytes)
     b.depth_out = c.take<uint32_t>(m);
     b.ids_in = c.take<uint32_t>(m);
     b.ids_out = c.take<uint32_t>(m);
+    b.clusters_a = c.take<int>(n);
+    b.clusters_b = c.take<int>(n);
+    b.nearest = c.take<int>(n);
+    b.merged = c.take<int>(n);
+    b.sizes = c.take<int>(m);
+    b.leaf_position = c.take<int>(n);
+    b.keep = c.take<uint32_t>(n);
+    b.position = c.take<uint32_t>(n);
     b.sort_temp = c.take<char>(sort_temp_bytes);
     b.sort_temp_bytes = sort_temp_bytes;
     b.total = c.used + 256;
@@ -476,7 +628,7 @@ void free_build_scratch(BuildScratch& s)
 }
 
 int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* d_src, int T, int tri_first, int node_base, int max_leaf,
-                   TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes, MeshBuildInfo* out)
+                   TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes, MeshBuildInfo* out, bool ploc)
 {
     if (T <= max_leaf || T < 2) return fail(FF_ERR_INVALID_ARG, "gpu_build_mesh: %d triangles fit one leaf", T);
     if (max_leaf < 1 || max_leaf > 8) return fail(FF_ERR_INVALID_ARG, "max_leaf_tris must be 1..8");
@@ -487,7 +639,10 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
                                       stream));
     FFB_HIP(rocprim::radix_sort_pairs(nullptr, temp_depth, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(T - 1), 0u,
                                       8u, stream));
-    const size_t sort_temp = temp_codes > temp_depth ? temp_codes : temp_depth;
+    size_t temp_scan = 0;
+    FFB_HIP(rocprim::exclusive_scan(nullptr, temp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)T, rocprim::plus<uint32_t>(), stream));
+    size_t sort_temp = temp_codes > temp_depth ? temp_codes : temp_depth;
+    if (temp_scan > sort_temp) sort_temp = temp_scan;
     const BuildBuffers sizes = carve_build(nullptr, T, sort_temp);
     int st = ensure_scratch(scratch, sizes.total);
     if (st != FF_OK) return st;
@@ -501,8 +656,37 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
     morton_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, T, b.bounds, b.keys_in, b.vals_in);
     size_t tb = b.sort_temp_bytes;
     FFB_HIP(rocprim::radix_sort_pairs(b.sort_temp, tb, b.keys_in, b.keys_out, b.vals_in, b.vals_out, (size_t)T, 0u, 63u, stream));
-    hierarchy_kernel<<<node_grid, kBuildBlock, 0, stream>>>(b.keys_out, T, b.left, b.right, b.first, b.last, b.node_parent, b.leaf_parent);
-    fit_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, b.left, b.right, b.node_parent, b.leaf_parent, b.boxes, b.arrivals);
+    const int* leaf_position = nullptr;
+    if (!ploc) {
+        hierarchy_kernel<<<node_grid, kBuildBlock, 0, stream>>>(b.keys_out, T, b.left, b.right, b.first, b.last, b.node_parent, b.leaf_parent);
+        fit_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, b.left, b.right, b.node_parent, b.leaf_parent, b.boxes, b.arrivals);
+    } else {
+        leaf_boxes_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, b.boxes, b.clusters_a);
+        int* cur = b.clusters_a;
+        int* nxt = b.clusters_b;
+        int n = T;
+        for (int iter = 0; n > 1; ++iter) {
+            if (iter > 4 * 64) return fail(FF_ERR_HIP, "gpu_build_mesh: clustering did not converge (%d clusters left)", n);
+            const int g = grid_for(n);
+            ploc_neighbour_kernel<<<g, kBuildBlock, 0, stream>>>(n, T, cur, b.boxes, b.nearest);
+            ploc_merge_kernel<<<g, kBuildBlock, 0, stream>>>(n, T, cur, b.nearest, b.boxes, b.left, b.right, b.node_parent, b.leaf_parent, b.sizes, b.counters,
+                                                             b.merged, b.keep);
+            size_t ts = b.sort_temp_bytes;
+            FFB_HIP(rocprim::exclusive_scan(b.sort_temp, ts, b.keep, b.position, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+            ploc_compact_kernel<<<g, kBuildBlock, 0, stream>>>(n, b.merged, b.keep, b.position, nxt, b.counters);
+            int left_over = 0;
+            FFB_HIP(hipMemcpyAsync(&left_over, b.counters + 3, sizeof(int), hipMemcpyDeviceToHost, stream));
+            FFB_HIP(hipStreamSynchronize(stream));
+            if (left_over < 1 || left_over >= n) return fail(FF_ERR_HIP, "gpu_build_mesh: clustering step went from %d to %d clusters", n, left_over);
+            n = left_over;
+            int* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        ploc_ranges_kernel<<<grid_for(2 * T - 1), kBuildBlock, 0, stream>>>(T, b.left, b.right, b.node_parent, b.leaf_parent, b.sizes, b.first, b.last,
+                                                                          b.leaf_position);
+        leaf_position = b.leaf_position;
+    }
     rank_key_kernel<<<node_grid, kBuildBlock, 0, stream>>>(T, max_leaf, b.first, b.last, b.node_parent, b.depth_in, b.ids_in, b.counters);
     tb = b.sort_temp_bytes;
     FFB_HIP(rocprim::radix_sort_pairs(b.sort_temp, tb, b.depth_in, b.depth_out, b.ids_in, b.ids_out, (size_t)(T - 1), 0u, 8u, stream));
@@ -514,8 +698,8 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
     if (depth >= (int)kNotEmitted) return fail(FF_ERR_UNSUPPORTED, "gpu_build_mesh: tree depth %d exceeds the builder's limit", depth);
     rank_scatter_kernel<<<grid_for(emitted), kBuildBlock, 0, stream>>>(emitted, b.ids_out, b.new_index);
     emit_kernel<<<grid_for(emitted), kBuildBlock, 0, stream>>>(T, emitted, max_leaf, tri_first, node_base, b.bounds, b.ids_out, b.new_index, b.left, b.right,
-                                                               b.first, b.last, b.boxes, d_nodes);
-    records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, tri_first, d_tris, d_normals);
+                                                               b.first, b.last, b.boxes, leaf_position, d_nodes);
+    records_kernel<<<tri_grid, kBuildBlock, 0, stream>>>(d_src, b.vals_out, T, tri_first, leaf_position, d_tris, d_normals);
     FFB_HIP(hipGetLastError());
     out->root = node_base;
     out->node_count = emitted;

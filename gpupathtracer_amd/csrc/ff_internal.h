@@ -88,6 +88,7 @@ struct CompiledScene {
 
 struct BvhBuildParams {
     int max_leaf_tris = 4; // <= 8
+    int device_leaf_tris = 2; // device builders: subtrees of up to this many triangles become one leaf (<= max_leaf_tris)
     int max_depth = 30;    // hard bound on inner-node depth (the traversal stack is sized from the built depth)
     int bins = 16;
     float c_trav = 1.2f;   // SAH cost of an inner-node visit relative to one triangle test

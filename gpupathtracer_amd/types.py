@@ -115,7 +115,7 @@ class FfBuildStats(C.Structure):
     ]
 
 
-BUILD_HOST_SAH, BUILD_GPU_LBVH = 0, 1
+BUILD_HOST_SAH, BUILD_GPU_LBVH, BUILD_GPU_PLOC = 0, 1, 2
 UPDATE_REFIT, UPDATE_REBUILD = 0, 1
 
 # device records as ff_debug_download_bvh returns them (gpupathtracer_amd/csrc/ff_internal.h)

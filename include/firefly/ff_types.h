@@ -174,13 +174,14 @@ typedef struct FfStats {
 /* Which builder produces the BVH (ff_set_builder). */
 typedef enum FfBuilder {
     FF_BUILD_HOST_SAH = 0, /* binned SAH on the host: best trees, for scenes uploaded once (the reference's case, kernel.cu:268-298) */
-    FF_BUILD_GPU_LBVH = 1  /* Morton-code LBVH built on the device: for geometry that changes between frames */
+    FF_BUILD_GPU_LBVH = 1, /* Morton-code LBVH built on the device: for geometry that changes between frames */
+    FF_BUILD_GPU_PLOC = 2  /* agglomerative clustering (PLOC) on the device: a few times the LBVH's build time, trees close to SAH quality */
 } FfBuilder;
 
 /* ff_update_mesh modes. */
 typedef enum FfMeshUpdate {
     FF_UPDATE_REFIT   = 0, /* keep the tree, recompute its boxes from the moved vertices */
-    FF_UPDATE_REBUILD = 1  /* rebuild the mesh's tree on the device (scene must have been uploaded with FF_BUILD_GPU_LBVH) */
+    FF_UPDATE_REBUILD = 1  /* rebuild the mesh's tree on the device (scene must have been uploaded with a device builder) */
 } FfMeshUpdate;
 
 /* Filled by ff_build_stats(): the last ff_upload_scene / ff_update_mesh / ff_update_transforms call. */

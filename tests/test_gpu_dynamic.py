@@ -22,10 +22,11 @@ def golden():
     return np.load(GOLDEN)
 
 
-@pytest.fixture()
-def lbvh_tracer():
+@pytest.fixture(params=[T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC], ids=["lbvh", "ploc"])
+def lbvh_tracer(request):
+    """A tracer whose uploads build their trees on the device (either device builder)."""
     with lib.Tracer(0) as t:
-        t.set_builder(T.BUILD_GPU_LBVH)
+        t.set_builder(request.param)
         yield t
 
 
@@ -103,7 +104,7 @@ def test_golden_frames_with_device_built_trees(lbvh_tracer, golden, name):
     scene, cam, params = build_case(name)
     lbvh_tracer.upload_scene(scene)
     bs = lbvh_tracer.build_stats()
-    assert bs.builder == T.BUILD_GPU_LBVH and bs.num_triangles == scene.triangle_count
+    assert bs.builder in (T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC) and bs.num_triangles == scene.triangle_count
     rgb8, rad = lbvh_tracer.render(cam, params)
     assert np.array_equal(rgb8, golden[name + "/rgb8"]), f"{name}: {(rgb8 != golden[name + '/rgb8']).any(axis=2).sum()} pixels differ"
     assert same_bits(rad, golden[name + "/radiance"]), f"{name}: radiance not bit-identical"
@@ -170,7 +171,7 @@ def _deform(triangles, phase):
     return out
 
 
-@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH], ids=["host_tree", "device_tree"])
+@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC], ids=["host_tree", "lbvh_tree", "ploc_tree"])
 @pytest.mark.parametrize("mode", [T.UPDATE_REFIT, T.UPDATE_REBUILD], ids=["refit", "rebuild"])
 def test_update_mesh_matches_fresh_upload_and_oracle(builder, mode):
     scene = scenes.cornell_wahoo_scene()
@@ -220,7 +221,7 @@ def test_refit_twice_then_rebuild(lbvh_tracer):
             assert same_bits(rad, fresh.render(cam, params)[1]), f"step {step}"
 
 
-@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH], ids=["host_tree", "device_tree"])
+@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC], ids=["host_tree", "lbvh_tree", "ploc_tree"])
 def test_update_transforms_matches_fresh_upload(builder):
     scene = scenes.cornell_wahoo_scene()
     gi = _mesh_index(scene, 0)

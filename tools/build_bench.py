@@ -19,7 +19,7 @@ def run(name, scene, cam, params):
     gi = [i for i, s in enumerate(scene._specs) if s[0] == T.GEOM_TRIANGLEMESH]
     big = max(gi, key=lambda i: len(scene._specs[i][4]))
     tris = scene._specs[big][4]
-    for builder, label in ((T.BUILD_HOST_SAH, "host SAH "), (T.BUILD_GPU_LBVH, "device LBVH")):
+    for builder, label in ((T.BUILD_HOST_SAH, "host SAH   "), (T.BUILD_GPU_LBVH, "device LBVH"), (T.BUILD_GPU_PLOC, "device PLOC")):
         with lib.Tracer(0) as t:
             t.set_builder(builder)
             t.upload_scene(scene)      # warm (allocations, code objects)
@@ -33,7 +33,7 @@ def run(name, scene, cam, params):
             moved = np.array(tris, copy=True); moved[:, 1:9:3] *= np.float32(1.01)
             t.update_mesh(big, moved, T.UPDATE_REFIT); t.update_mesh(big, moved, T.UPDATE_REFIT)
             print(f"{name} {label} refit  : {fmt(t.build_stats())}")
-            if builder == T.BUILD_GPU_LBVH:
+            if builder != T.BUILD_HOST_SAH:
                 t.update_mesh(big, moved, T.UPDATE_REBUILD); t.update_mesh(big, moved, T.UPDATE_REBUILD)
                 print(f"{name} {label} rebuild: {fmt(t.build_stats())}")
             t.update_transforms(scene)

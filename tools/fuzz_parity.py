@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised exactness fuzz on the GPU: random scenes (meshes, planes, spheres under random rotations / non-uniform
-scales, random materials), random cameras; the BVH kernel (host SAH trees and device LBVH trees) must reproduce the
+scales, random materials), random cameras; the BVH kernel (host SAH trees, device LBVH and PLOC trees) must reproduce the
 brute-force kernel (the reference's loop, kernel.cu:133-155) bit for bit: radiance, rgb8 and ray counts.
 Usage: fuzz_parity.py [cases] [seed]"""
 import os
@@ -75,21 +75,22 @@ def run(cases, seed, verbose=True):
     """BVH (both tree kinds) against brute force.  Returns (mismatching renders, rays per kernel)."""
     rng = np.random.default_rng(seed)
     bad, total_rays = 0, 0
-    with lib.Tracer(0) as sah, lib.Tracer(0) as lbvh:
+    with lib.Tracer(0) as sah, lib.Tracer(0) as lbvh, lib.Tracer(0) as ploc:
         lbvh.set_builder(T.BUILD_GPU_LBVH)
+        ploc.set_builder(T.BUILD_GPU_PLOC)
         for c in range(cases):
             scene = rand_scene(rng)
             w, h, cam = rand_view(rng)
             p = rand_params(rng, w, h, T.TRACE_BVH)
             out = {}
-            for name, tr, mode in (("sah", sah, T.TRACE_BVH), ("lbvh", lbvh, T.TRACE_BVH), ("brute", sah, T.TRACE_BRUTE_FORCE)):
+            for name, tr, mode in (("sah", sah, T.TRACE_BVH), ("lbvh", lbvh, T.TRACE_BVH), ("ploc", ploc, T.TRACE_BVH), ("brute", sah, T.TRACE_BRUTE_FORCE)):
                 if name != "brute":
                     tr.upload_scene(scene)
                 p.trace_mode = mode
                 rgb8, rad = tr.render(cam, p)
                 out[name] = (rgb8, rad, tr.stats().rays_traced)
             total_rays += out["brute"][2]
-            for name in ("sah", "lbvh"):
+            for name in ("sah", "lbvh", "ploc"):
                 same = (np.array_equal(out[name][0], out["brute"][0]) and np.array_equal(out[name][1].view(np.uint32), out["brute"][1].view(np.uint32))
                         and out[name][2] == out["brute"][2])
                 if not same:
