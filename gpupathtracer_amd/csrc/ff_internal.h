@@ -90,7 +90,7 @@ struct BvhBuildParams {
     int max_leaf_tris = 2; // <= 8 (2 measured best on the benchmark scene: 8.1 node visits + 1.7 triangle tests per ray vs 7.9 + 1.9 with 4)
     int device_leaf_tris = 2; // device builders: subtrees of up to this many triangles become one leaf (<= max_leaf_tris)
     int max_depth = 30;    // hard bound on inner-node depth (the traversal stack is sized from the built depth)
-    int bins = 16;
+    int bins = 64;
     float c_trav = 1.2f;   // SAH cost of an inner-node visit relative to one triangle test
 };
 
