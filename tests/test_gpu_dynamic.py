@@ -312,3 +312,27 @@ def test_progressive_accumulation_matches_oracle_frames(tracer):
     _, first = tracer.render(cam, params)
     rgb8, rad = tracer.render_progressive(cam, params, 0)  # restart: a single frame again
     assert same_bits(rad, first)
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 5, 7])
+def test_tiny_meshes_on_every_builder(count):
+    """Meshes at and around the leaf size (one-leaf trees are assembled on the host, the rest built on the device)."""
+    wahoo = scenes.load_mesh("wahoo")
+    tris = wahoo[100:100 + count] * np.float32(1.0)
+    tris[:, 0:9] *= np.float32(4.0)  # make them visible
+    scene = scenes.reference_scene(tris)
+    cam = scenes.posed_camera(64, 48, **POSES["oblique"])
+    params = lib.render_params(64, 48, 1, 1, 1, T.TRACE_BVH, T.SHADE_NORMAL_DEBUG, T.GRID_FULL, 0)
+    o_rgb8, o_rad = oracle_render(scene, cam, params)
+    for builder in (T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC):
+        with lib.Tracer(0) as t:
+            t.set_builder(builder)
+            t.upload_scene(scene)
+            check_tree(*t.download_bvh(len(scene)))
+            rgb8, rad = t.render(cam, params)
+            assert np.array_equal(rgb8, o_rgb8) and same_bits(rad, o_rad), (builder, count)
+            if builder != T.BUILD_HOST_SAH:
+                t.update_mesh(_mesh_index(scene), tris, T.UPDATE_REBUILD)
+            t.update_mesh(_mesh_index(scene), tris, T.UPDATE_REFIT)
+            check_tree(*t.download_bvh(len(scene)))
+            assert same_bits(t.render(cam, params)[1], o_rad)
