@@ -207,7 +207,8 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.nodes = s->d_nodes;
     const int block_threads = prm->trace_mode == FF_TRACE_BVH ? s->block_threads : kBlockThreads;
     k.stack_depth = s->max_depth + 1; // at most one pending sibling per level above the cursor, plus one spare slot
-    const bool use_pool = prm->trace_mode == FF_TRACE_BVH && s->scheduler == 1;
+    // (the experimental pool scheduler handles single-chunk scenes only)
+    const bool use_pool = prm->trace_mode == FF_TRACE_BVH && s->scheduler == 1 && s->num_geoms <= 32;
     int fit = max_lds_nodes(k.stack_depth, use_pool ? 1024 : block_threads, s->num_geoms);
     if (use_pool) fit -= (int)((pool_list_bytes(s->pool_slots, 1024) + sizeof(BvhNode) - 1) / sizeof(BvhNode));
     k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;

@@ -10,7 +10,8 @@ namespace ff {
 constexpr int kBlockThreads = 512;        // default workgroup: 8 waves, one workgroup per CU shares one LDS copy of the BVH top
 constexpr int kBlockThreadsMax = 1024;    // alternative: 16 waves per workgroup (4 per SIMD), smaller node cache next to the stacks
 constexpr int kLdsBudgetBytes = 160 * 1024;
-constexpr int kMaxGeometriesBvh = 32;     // BVH mode: one candidate bit per mesh in a 32-bit mask, records resident in LDS (288 B each)
+constexpr int kMaxGeometriesBvh = 128;    // BVH mode: geometry records resident in LDS (288 B each); queries work through them in chunks of 32
+                                          // (one candidate bit per record of the chunk)
 constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
 
 // Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).

@@ -301,13 +301,16 @@ struct Lds {
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
     const float4* smooth_normals; // non-null: triangle hits carry the interpolated vertex normal (FF_SHADE_DIFFUSE_PATH_SMOOTH)
+    int last_base;  // first record of the last chunk of 32 geometry records: ((num_geoms - 1) / 32) * 32
 };
 
-__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr)
+__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
+                                        int last_base = 0)
 {
     Lds L;
     L.num_quads = num_quads;
     L.smooth_normals = smooth_normals;
+    L.last_base = last_base;
     L.node_count = lds_nodes;
     L.stride = block;
     L.stack_base = lds_nodes * 16 + tid;
@@ -442,7 +445,8 @@ struct Pending {
 struct Segment {
     BestId best;
     Pending pend;
-    unsigned meshes;           // candidate meshes not started yet (bit = record index; BVH mode handles <= 32 geometries)
+    unsigned meshes;           // candidate meshes not started yet (bit = record index - base)
+    int base;                  // first geometry record of the chunk of 32 the query is working on (0 unless the scene has > 32)
     int cur, sp, mesh;         // traversal cursor (inner >= 0, leaf < 0, kDone), stack height, record index of the current mesh
     Ray osr;                   // object-space ray of the current mesh
     float ix, iy, iz, ox, oy, oz; // 1/d and -o/d of osr (box tests)
@@ -554,20 +558,15 @@ __device__ __forceinline__ bool offer(float d, int g, int rec, Pending& pend, co
 // of kernel.cu:138: the hit position on the unit quad does not depend on the length of the object-space direction, so
 // the screen works on the un-normalised direction M^-1*d, for which the ray parameter is the world-space parameter.
 // Anything within the margins (quad edges, t ~ 0, |n.d| ~ 1e-7) is decided by the exact reference test at once.
+// One chunk of up to 32 geometry records starting at S.base: screen its planes / spheres and collect its candidate meshes.
+// Scenes of up to 32 geometries (the reference has 5) are a single chunk; larger scenes are worked through chunk by chunk,
+// each query carrying its best / pending candidate across chunks.
 template <bool STATS>
-__device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
-                                              const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+__device__ __forceinline__ void scan_chunk(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+                                           const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
-    S.best.dist = kInf; // kernel.cu:131
-    S.best.geom = -1;
-    S.best.rec = -1;
-    S.pend.dist = kInf;
-    S.pend.geom = -1;
-    S.pend.rec = -1;
-    S.cur = kDone;
-    S.sp = 0;
-    S.mesh = -1;
-    S.resume = 0;
+    const int base = S.base;
+    const int prim_end = min(num_planes, base + 32), geom_end = min(num_geoms, base + 32);
     const float wlen = __builtin_amdgcn_rcpf(inv_length(wr)); // |world direction| (1 for the integrator's rays)
 
     // Stage 1, wave-uniform: which quads can the ray reach at all?  The padded world box of a quad is flat, so for the
@@ -576,15 +575,15 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     if (STATS) tb0 = __builtin_amdgcn_s_memtime();
     const WorldSlab ws = make_world_slab(wr);
     unsigned quads = 0u;
-    for (int g = 0; g < num_planes; ++g) {
+    for (int g = base; g < prim_end; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-        if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << g;
+        if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << (g - base);
     }
     if (STATS) tb1 = __builtin_amdgcn_s_memtime();
     // Stage 2, per lane: screen the lane's own candidates (records from the LDS copy at per-lane addresses).
     for (int guard = 0; __ballot(quads != 0u) != 0ull && guard < 32; ++guard) {
         if (quads == 0u) continue;
-        const int g = __ffs((int)quads) - 1;
+        const int g = base + __ffs((int)quads) - 1;
         quads &= quads - 1u;
         if (STATS) { cnt.planes += 1; probe_round(cnt.plane_rounds); }
         if (g >= L.num_quads) {
@@ -646,15 +645,34 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     // meshes: conservative world-box test against what the planes already found
     S.meshes = 0u;
     const float limit = fminf(S.best.dist, S.pend.dist);
-    for (int g = num_planes; g < num_geoms; ++g) {
+    for (int g = max(num_planes, base); g < geom_end; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << g;
+        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << (g - base);
     }
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
     if (STATS) {
         const unsigned long long tb3 = __builtin_amdgcn_s_memtime();
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_b1 += tb1 - tb0; cnt.t_b2 += tb2 - tb1; cnt.t_b3 += tb3 - tb2; }
     }
+}
+
+// Start a closest-hit query: empty candidate slots, then the first chunk of geometry records.
+template <bool STATS>
+__device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+                                              const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+{
+    S.best.dist = kInf; // kernel.cu:131
+    S.best.geom = -1;
+    S.best.rec = -1;
+    S.pend.dist = kInf;
+    S.pend.geom = -1;
+    S.pend.rec = -1;
+    S.cur = kDone;
+    S.sp = 0;
+    S.mesh = -1;
+    S.resume = 0;
+    S.base = 0;
+    scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
 }
 
 // Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
@@ -678,7 +696,7 @@ __device__ __forceinline__ void pop_subtree(const Lds& L, Segment& S)
 // Idle lane with candidate meshes left: enter the next one.
 __device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Segment& S)
 {
-    const int g = __ffs((int)S.meshes) - 1;
+    const int g = S.base + __ffs((int)S.meshes) - 1;
     S.meshes &= S.meshes - 1u;
     const int root = lds_geom_i4(L, g, 17).x;
     if (root < 0) return;
@@ -803,7 +821,9 @@ __device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __
     best.cx = H.cx; best.cy = H.cy; best.cz = H.cz;
 }
 
-__device__ __forceinline__ bool segment_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
+// Nothing left to do in the current chunk of geometry records / in the whole query.
+__device__ __forceinline__ bool chunk_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
+__device__ __forceinline__ bool segment_done(const Lds& L, const Segment& S) { return chunk_done(S) && S.base >= L.last_base; }
 
 // Advance the queries of the calling lanes: mesh starts, inner-node phases, leaf phases and near-tie resolutions alternate
 // wave-wide until every calling lane is done or `budget` inner-node rounds have been spent (budget <= 0: no limit).
@@ -857,6 +877,11 @@ __device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRec
     if (STATS) probe_round(cnt.segment_rounds);
     begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
     traverse_budget<STATS>(L, tris, nodes, wr, S, cnt, 0, 64);
+    while (S.base < L.last_base) { // > 32 geometries: the remaining chunks of records (uniform: every lane walks all chunks)
+        S.base += 32;
+        scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+        traverse_budget<STATS>(L, tris, nodes, wr, S, cnt, 0, 64);
+    }
     finish_segment(L, tris, wr, S, best);
     cnt.rays += 1;
 }
@@ -1289,7 +1314,8 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
+                           EXTRAS ? ((p.num_geoms - 1) >> 5) << 5 : 0);
     stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1304,6 +1330,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
     S.scale = 1.f;
     S.tbound = 0.f;
+    S.base = 0;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
@@ -1311,7 +1338,15 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         // Lanes whose query is finished (or that have none) resolve + shade + spawn together; lanes still traversing skip.
-        const bool setup = !inflight || segment_done(S);
+        if (EXTRAS && L.last_base > 0) {
+            // scenes of more than 32 geometries: queries that finished a chunk of records move on to the next one
+            const bool advance = inflight && chunk_done(S) && S.base < L.last_base;
+            if (__ballot(advance) != 0ull && advance) {
+                S.base += 32;
+                scan_chunk<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
+            }
+        }
+        const bool setup = !inflight || segment_done(L, S);
         Best best;
         bool hit = false;
         if (setup && inflight) {
@@ -1430,6 +1465,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
     S.scale = 1.f;
     S.tbound = 0.f;
+    S.base = 0;
 
     for (int guard = 0; guard < (1 << 28); ++guard) {
         const int running = __popcll(__ballot(my_slot >= 0));
@@ -1529,14 +1565,14 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
         }
         if (my_slot >= 0) {
             traverse_budget<STATS>(L, p.tris, p.nodes, ray, S, cnt, p.setup_threshold, p.leaf_threshold);
-            if (segment_done(S)) {
+            if (segment_done(L, S)) {
                 const int j = my_slot;
                 pool_set_f(W, j, kBestDist, S.best.dist); pool_set_u(W, j, kBestGeom, (unsigned)S.best.geom); pool_set_u(W, j, kBestRec, (unsigned)S.best.rec);
                 pool_set_f(W, j, kPendDist, S.pend.dist); pool_set_u(W, j, kPendGeom, (unsigned)S.pend.geom); pool_set_u(W, j, kPendRec, (unsigned)S.pend.rec);
             }
         }
         {
-            const bool done = my_slot >= 0 && segment_done(S);
+            const bool done = my_slot >= 0 && segment_done(L, S);
             const unsigned long long m_done = __ballot(done);
             if (done) {
                 finished[n_finished + __popcll(m_done & ((1ull << lane) - 1ull))] = (unsigned short)my_slot;
@@ -1585,7 +1621,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatchParams p)
 {
     const int tid = threadIdx.x;
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads);
+    const Lds L = make_lds(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, ((p.num_geoms - 1) >> 5) << 5);
     if (MODE == FF_TRACE_BVH) stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);
     const int i = blockIdx.x * kBlockThreads + tid;
@@ -1779,7 +1815,7 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
             return hipGetLastError();
         }
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
-        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr; // any build-defined extra: the full kernel
+        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr || p.num_geoms > 32; // any extra: the full kernel
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
         if (collect_stats) {                                                                                              \

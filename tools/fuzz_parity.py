@@ -35,10 +35,20 @@ def rand_bxdf(rng):
     return scenes.make_bxdf(T.BXDF_EMITTER, emissive=col, intensity=float(rng.uniform(1.0, 4.0)))
 
 
-def rand_scene(rng, small=False):
-    """1-3 meshes, 0-6 planes (axis-aligned, 45-degree and arbitrary rotations), 0-3 spheres, one large emitter above."""
+def rand_scene(rng, small=False, crowd=0):
+    """1-3 meshes, 0-6 planes (axis-aligned, 45-degree and arbitrary rotations), 0-3 spheres, one large emitter above;
+    crowd > 0 adds that many small cubes / spheres / quads (scenes of more than 32 geometries: several record chunks)."""
     s = scenes.Scene()
     names = ["cube", "sphere"] if small else list(NORM)
+    for _ in range(crowd):
+        k = int(rng.integers(0, 3))
+        pos, rot = tuple(rng.uniform(-3, 3, 3)), tuple(rng.uniform(-180, 180, 3))
+        if k == 0:
+            s.add_mesh(meshes()["cube"], pos, rot, tuple(float(v) for v in rng.uniform(0.2, 0.7, 3)), rand_bxdf(rng))
+        elif k == 1:
+            s.add_sphere(float(rng.uniform(0.15, 0.5)), pos, rot, (1, 1, 1), rand_bxdf(rng))
+        else:
+            s.add_plane(pos, rot, tuple(float(v) for v in rng.uniform(0.3, 1.5, 3)), rand_bxdf(rng))
     for _ in range(int(rng.integers(1, 3 if small else 4))):
         name = names[int(rng.integers(0, len(names)))]
         sc = NORM[name] * rng.uniform(0.5, 2.0, 3)
@@ -71,15 +81,15 @@ def rand_params(rng, w, h, mode):
     return lib.render_params(w, h, bounces, spp, seed, mode, shade, T.GRID_FULL, 0)
 
 
-def run(cases, seed, verbose=True):
-    """BVH (both tree kinds) against brute force.  Returns (mismatching renders, rays per kernel)."""
+def run(cases, seed, verbose=True, crowd_fraction=0.15):
+    """BVH (all tree kinds) against brute force.  Returns (mismatching renders, rays per kernel)."""
     rng = np.random.default_rng(seed)
     bad, total_rays = 0, 0
     with lib.Tracer(0) as sah, lib.Tracer(0) as lbvh, lib.Tracer(0) as ploc:
         lbvh.set_builder(T.BUILD_GPU_LBVH)
         ploc.set_builder(T.BUILD_GPU_PLOC)
         for c in range(cases):
-            scene = rand_scene(rng)
+            scene = rand_scene(rng, crowd=int(rng.integers(30, 110)) if rng.random() < crowd_fraction else 0)
             w, h, cam = rand_view(rng)
             p = rand_params(rng, w, h, T.TRACE_BVH)
             out = {}
