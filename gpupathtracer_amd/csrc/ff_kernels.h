@@ -26,6 +26,7 @@ struct KParams {
     // work decomposition: local rows of this part, in strips
     int strip_rows, part, num_parts, local_rows;
     unsigned total_items; // work items of this launch: pix_items x (block_end - block_begin)
+    int items_per_fetch;  // items a lane takes per queue fetch (1 for long items; more when an item is only a few samples)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
     // integrator

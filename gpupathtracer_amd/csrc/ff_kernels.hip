@@ -1049,6 +1049,8 @@ struct Path {
     Ray ray;       // current world-space ray
     float bx, by, bz; // throughput
     float ax, ay, az; // running sum over samples
+    unsigned run_next, run_stride; // work items this lane still owns from its last queue fetch: run_next, run_next + run_stride, ...
+    int run_left;
 };
 
 // kernel.cu:197-205 for global pixel (x, y): origin = camera position, direction through the pixel corner.
@@ -1091,16 +1093,31 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
     bool got = false, exhausted = false;
     for (;;) {
         const bool want = !got && !exhausted;
-        const unsigned long long m = __ballot(want);
-        if (m == 0ull) break;
-        unsigned base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(p.queue, (unsigned)__popcll(m));
-        base = __shfl(base, leader);
+        if (__ballot(want) == 0ull) break;
+        // Lanes that used up their run fetch a new one: one atomic per wave for items_per_fetch items per asking lane,
+        // dealt so that at every step the lanes of the fetch hold consecutive items (base + step * lanes + rank).  With
+        // short items (few samples per pixel) a fetch per item would saturate the counter's memory channel.
+        const bool fetch = want && P.run_left == 0;
+        const unsigned long long m = __ballot(fetch);
+        if (m != 0ull) {
+            const unsigned cnt = (unsigned)__popcll(m);
+            unsigned base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(p.queue, cnt * (unsigned)p.items_per_fetch);
+            base = __shfl(base, leader);
+            if (fetch) {
+                P.run_next = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                P.run_stride = cnt;
+                P.run_left = p.items_per_fetch;
+            }
+        }
         if (want) {
-            const unsigned item = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            const unsigned item = P.run_next;
+            P.run_next += P.run_stride;
+            --P.run_left;
             if (item >= p.total_items) {
                 exhausted = true;
+                P.run_left = 0;
             } else {
                 // an item is one sample block of one pixel; pixels walk 8x8 tiles of the local image (padding items and
                 // untraced pixels are consumed and skipped), blocks are the slow index
@@ -1295,6 +1312,9 @@ __device__ __forceinline__ void init_path(Path& P)
     P.bitem = 0; P.send = 0; P.gxy = 0; P.s = 0; P.b = 0;
     P.pdx = P.pdy = 0.f; P.pdz = 1.f;
     P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    P.run_next = 0u;
+    P.run_stride = 1u;
+    P.run_left = 0;
     P.bx = P.by = P.bz = 1.f;
     P.ax = P.ay = P.az = 0.f;
 }
