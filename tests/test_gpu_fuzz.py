@@ -8,7 +8,7 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 import fuzz_parity as fz  # noqa: E402
-from gpupathtracer_amd import lib  # noqa: E402
+from gpupathtracer_amd import lib, scenes  # noqa: E402
 from gpupathtracer_amd import types as T  # noqa: E402
 from oracle_lib import oracle_render  # noqa: E402
 
@@ -55,3 +55,42 @@ def test_random_scene_equals_oracle(tracer, seed):
     o_rgb8, o_rad = oracle_render(scene, cam, p, threads=16)
     assert np.array_equal(rgb8, o_rgb8)
     assert np.array_equal(rad.view(np.uint32), o_rad.view(np.uint32))
+
+
+def _edge_scenes():
+    cube = scenes.load_mesh("cube")
+    light = lambda: scenes.make_bxdf(T.BXDF_EMITTER, emissive=(1, 1, 1), intensity=3.0)
+    grey = lambda: scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(0.7, 0.7, 0.7))
+    glass = lambda: scenes.make_bxdf(T.BXDF_GLASS, specular=(1, 1, 1), transmittance=(0.9, 0.9, 1.0), ior=1.5)
+    out = {}
+    out["planes_only"] = scenes.Scene().add_plane((0, 0, -3), (0, 0, 0), (8, 8, 8), grey()).add_plane((0, 3, 0), (90, 0, 0), (8, 8, 8), light()).finalize()
+    out["mesh_only"] = scenes.Scene().add_mesh(cube, (0, 0, -2), (20, 30, 0), (2, 2, 2), light()).finalize()
+    out["one_triangle"] = scenes.Scene().add_mesh(cube[:1] * np.float32(6.0), (0, 0, -3), (0, 180, 0), (1, 1, 1), light()).finalize()
+    out["sphere_only"] = scenes.Scene().add_sphere(1.0, (0, 0, -3), (0, 0, 0), (1, 1, 1), light()).finalize()
+    # the camera sits inside a big emitting sphere and inside a glass sphere inside it
+    out["inside_spheres"] = (scenes.Scene().add_sphere(20.0, (0, 0, 0), (0, 0, 0), (1, 1, 1), light())
+                             .add_sphere(3.5, (0, 0, 4), (0, 0, 0), (1, 1, 1), glass()).add_mesh(cube, (0, 0, -4), (0, 0, 0), (1, 1, 1), grey()).finalize())
+    # far from the origin and strongly non-uniform scales
+    out["far_and_stretched"] = (scenes.Scene().add_mesh(cube, (1000, 1000, -1005), (10, 20, 30), (8, 0.05, 3), grey())
+                                .add_sphere(1.0, (1000, 1002, -1004), (0, 0, 45), (0.2, 3, 1), grey())
+                                .add_plane((1000, 1004, -1004), (90, 0, 0), (30, 30, 30), light()).finalize())
+    return out
+
+
+@pytest.mark.parametrize("name", ["planes_only", "mesh_only", "one_triangle", "sphere_only", "inside_spheres", "far_and_stretched"])
+def test_edge_scenes_equal_oracle(name):
+    scene = _edge_scenes()[name]
+    pos = (1000.0, 1000.5, -998.0) if name == "far_and_stretched" else (0.2, 0.3, 4.0)
+    cam = scenes.posed_camera(48, 36, position=pos, yaw=-92.0, pitch=-3.0)
+    for shade, bounces, spp in ((T.SHADE_NORMAL_DEBUG, 1, 1), (T.SHADE_DIFFUSE_PATH, 5, 3), (T.SHADE_DIFFUSE_PATH_SMOOTH, 3, 2)):
+        p = lib.render_params(48, 36, bounces, spp, 42, T.TRACE_BVH, shade, T.GRID_FULL, 0)
+        o_rgb8, o_rad = oracle_render(scene, cam, p, threads=16)
+        for builder in (T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC):
+            with lib.Tracer(0) as t:
+                t.set_builder(builder)
+                t.upload_scene(scene)
+                for mode in (T.TRACE_BVH, T.TRACE_BRUTE_FORCE):
+                    p.trace_mode = mode
+                    rgb8, rad = t.render(cam, p)
+                    assert np.array_equal(rgb8, o_rgb8), (name, shade, builder, mode)
+                    assert np.array_equal(rad.view(np.uint32), o_rad.view(np.uint32)), (name, shade, builder, mode)
