@@ -65,7 +65,7 @@ def _edge_scenes():
     out = {}
     out["planes_only"] = scenes.Scene().add_plane((0, 0, -3), (0, 0, 0), (8, 8, 8), grey()).add_plane((0, 3, 0), (90, 0, 0), (8, 8, 8), light()).finalize()
     out["mesh_only"] = scenes.Scene().add_mesh(cube, (0, 0, -2), (20, 30, 0), (2, 2, 2), light()).finalize()
-    out["one_triangle"] = scenes.Scene().add_mesh(cube[:1] * np.float32(6.0), (0, 0, -3), (0, 180, 0), (1, 1, 1), light()).finalize()
+    out["one_triangle"] = scenes.Scene().add_mesh(cube[:1] * np.float32(6.0), (0, 0, -3), (0, 0, 0), (1, 1, 1), light()).finalize()
     out["sphere_only"] = scenes.Scene().add_sphere(1.0, (0, 0, -3), (0, 0, 0), (1, 1, 1), light()).finalize()
     # the camera sits inside a big emitting sphere and inside a glass sphere inside it
     out["inside_spheres"] = (scenes.Scene().add_sphere(20.0, (0, 0, 0), (0, 0, 0), (1, 1, 1), light())
