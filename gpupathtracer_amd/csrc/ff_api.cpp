@@ -73,7 +73,7 @@ struct FfState {
     int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
-    unsigned long long raw_counters[24] = {};
+    unsigned long long raw_counters[28] = {};
     // GL interop
     hipGraphicsResource* pbo_resource = nullptr;
     int pbo_width = 0, pbo_height = 0;
@@ -247,7 +247,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced and missed pixels read 0
     if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
     if (radiance_dev) FF_HIP(hipMemsetAsync(radiance_dev, 0, local_pixels * 3 * sizeof(float), st));
-    FF_HIP(hipMemsetAsync(s->d_counters, 0, 24 * sizeof(unsigned long long), st));
+    FF_HIP(hipMemsetAsync(s->d_counters, 0, 28 * sizeof(unsigned long long), st));
     FF_HIP(hipEventRecord(s->ev_begin, st));
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
@@ -261,7 +261,7 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     FF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     FF_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
-    unsigned long long c[24];
+    unsigned long long c[28];
     FF_HIP(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
     std::memcpy(s->raw_counters, c, sizeof c);
     s->stats.rays_traced = c[0];
@@ -310,7 +310,7 @@ int ff_create(FfState** out_state, int device_id)
         delete s;
         return fail(FF_ERR_HIP, "ff_create: kernel preparation failed: %s (is this a gfx950 device?)", hipGetErrorString(pe));
     }
-    if (hipMalloc((void**)&s->d_queue, 64) != hipSuccess || hipMalloc((void**)&s->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&s->d_queue, 64) != hipSuccess || hipMalloc((void**)&s->d_counters, 28 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         ff_destroy(s);
         return fail(FF_ERR_HIP, "ff_create: allocating work buffers failed");
@@ -989,11 +989,11 @@ int ff_set_collect_stats(FfState* s, int on)
     return FF_OK;
 }
 
-int ff_debug_counters(FfState* s, unsigned long long* out24)
+int ff_debug_counters(FfState* s, unsigned long long* out28)
 {
     clear_error();
-    if (!s || !out24) return fail(FF_ERR_INVALID_ARG, "ff_debug_counters: null argument");
-    std::memcpy(out24, s->raw_counters, sizeof s->raw_counters);
+    if (!s || !out28) return fail(FF_ERR_INVALID_ARG, "ff_debug_counters: null argument");
+    std::memcpy(out28, s->raw_counters, sizeof s->raw_counters);
     return FF_OK;
 }
 

@@ -1354,6 +1354,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
+    const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
     for (;;) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
@@ -1386,6 +1387,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (setup && !active && !exhausted) {
             active = acquire_pixel(p, lane, P);
             exhausted = !active;
+            if (STATS && exhausted) atomicMax(&p.counters[23], ~(unsigned long long)wall_clock64()); // (complemented) first lane to find the queue empty
         }
         if (STATS) t3 = __builtin_amdgcn_s_memtime();
         if (setup && active) {
@@ -1411,6 +1413,8 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         atomicAdd(&p.counters[7], tphase[3]);
         atomicAdd(&p.counters[13], tphase[4]);
         atomicMax(&p.counters[22], tphase[0] + tphase[1] + tphase[2] + tphase[3] + tphase[4]); // slowest wave
+        atomicMax(&p.counters[24], ~(unsigned long long)wave_t0); // (complemented) first wave start, 100 MHz wall clock
+        atomicMax(&p.counters[25], (unsigned long long)wall_clock64()); // last wave end
     }
     flush_counters(p, lane, cnt, STATS);
 }

@@ -248,7 +248,7 @@ class Tracer:
         return int(buf[0]), int(buf[1])
 
     def debug_counters(self):
-        buf = (C.c_ulonglong * 24)()
+        buf = (C.c_ulonglong * 28)()
         check(self._lib.ff_debug_counters(self._state, buf))
         return list(buf)
 

@@ -188,12 +188,14 @@ FF_API int ff_save_ppm(const char* path, const unsigned char* rgb8, int width, i
 FF_API int ff_set_collect_stats(FfState* state, int on);
 FF_API int ff_stats(FfState* state, FfStats* out);
 
-/* Raw device counters of the last instrumented render (ff_set_collect_stats(1)), 24 values: [0] rays [1] inner-node
+/* Raw device counters of the last instrumented render (ff_set_collect_stats(1)), 28 values: [0] rays [1] inner-node
  * visits [2] triangle tests [3] plane tests (all summed over lanes) [8] inner-step rounds [9] leaf rounds [10] triangle
  * rounds [11] plane rounds [12] segment rounds (wave-level executions of each phase): lanes / (64 * rounds) is the SIMD
  * occupancy of that phase; [4..7],[13] wave cycles spent in resolve / shade / acquire / begin / traverse; [14] plane-only queries [15] exact plane
- * tests; [16..18] wave cycles in mesh starts / inner-node phases / leaf phases. */
-FF_API int ff_debug_counters(FfState* state, unsigned long long* out24);
+ * tests; [16..18] wave cycles in mesh starts / inner-node phases / leaf phases; [19..21] the three parts of the begin phase; [22] the
+ * slowest wave's loop cycles; [23..25] 100 MHz wall clock, complemented / complemented / plain: first lane to find the work
+ * queue empty, first wave start, last wave end. */
+FF_API int ff_debug_counters(FfState* state, unsigned long long* out28);
 
 /* Self-check of the kernels' arithmetic: their correctly rounded 1/x and sqrt(x) against the compiler's IEEE expansions on
  * every one of the 2^32 float bit patterns; out_mismatches2[0] / [1] must come back 0 (a few milliseconds). */

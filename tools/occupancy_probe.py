@@ -46,3 +46,7 @@ if tb:
     print(f"begin split: quad boxes {c[19] / tb:.3f}  quad screens {c[20] / tb:.3f}  mesh boxes {c[21] / tb:.3f}   cycles per segment round {tb / max(sr, 1):.0f}")
 loop = c[4] + c[5] + c[6] + c[7] + c[13]
 print(f"stamped loop time per wave: mean {loop / 4096 / 1e6:.2f} M ticks, slowest wave {c[22] / 1e6:.2f} M; kernel {st.kernel_ms:.2f} ms = {st.kernel_ms * 2.4:.2f} M cycles at 2.4 GHz")
+M = (1 << 64) - 1
+if c[23] and c[24] and c[25]:
+    t_start, t_empty, t_end = M - c[24], M - c[23], c[25]
+    print(f"wall clock: launch {(t_end - t_start) / 100:.0f} us, of which the queue was empty for the last {(t_end - t_empty) / 100:.0f} us (the tail)")
