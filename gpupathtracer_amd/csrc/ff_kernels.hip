@@ -4,18 +4,20 @@
 // triangles, shade, 8-bit store) is restructured here as a persistent mega-kernel:
 //
 //   * one workgroup per CU; the top of the BVH node array and all geometry records are staged ONCE per workgroup into
-//     LDS (64-byte nodes, both child boxes per node) and every lane keeps its traversal stack in LDS (lane-strided, so
-//     stack pushes/pops are bank-conflict free);
-//   * lanes pull (pixel) work items from one global counter with a wave-wide ballot + prefix compaction, and a lane
-//     owns its pixel for all samples: terminated paths regenerate in place;
-//   * the BVH kernel is a per-lane state machine: lanes whose ray has finished traversal wait until enough of them
-//     have gathered (or nobody is traversing any more), then resolve/shade/spawn their next ray TOGETHER while the
-//     unfinished lanes keep their traversal state; traversal itself alternates inner-node and leaf steps wave-wide.
-//     This keeps the 64 lanes of a wave occupied although neighbouring rays need very different amounts of work;
+//     LDS (64-byte nodes with both child boxes, kept as four planes of 16-byte quarters so that a wave's reads spread over
+//     all banks) and every lane keeps its traversal stack in LDS (lane-strided: pushes / pops are bank-conflict free);
+//   * lanes pull (pixel, sample block) work items from one global counter with a wave-wide ballot + prefix compaction
+//     (several short items per fetch when a frame has few samples per pixel); a lane sums its block's samples in order,
+//     terminated paths regenerate in place, and a combine pass adds a pixel's blocks in order;
+//   * traversal is time-sliced: after a budget of inner-node rounds the lanes whose query is complete resolve, shade and
+//     spawn their next ray TOGETHER while the long-tail lanes keep their traversal state; inside a slice the wave
+//     alternates inner-node phases and leaf phases.  This keeps the 64 lanes occupied although neighbouring rays need
+//     very different amounts of work;
 //   * the per-pixel camera matrix work of kernel.cu:203 is hoisted to the host; the per-hit 4x4 inverse of
 //     kernel.cu:117 is hoisted to the scene compiler.
 //
-// Numerics: the file is compiled with -ffp-contract=off and IEEE-correct sqrt/divide.  Every value that decides or
+// Numerics: the file is compiled with -ffp-contract=off and IEEE-correct sqrt/divide (1/x and sqrt through lean sequences
+// that are verified bit-identical to the IEEE expansions on all 2^32 inputs).  Every value that decides or
 // becomes part of a hit (object-space ray, Möller-Trumbore, world point, world distance, normal) is computed with
 // the reference's / glm's exact operation order, so hits are bit-identical to the brute-force reference loop.  Only
 // pruning (box tests, candidate screening) uses fused multiply-adds and approximate reciprocals, always with explicit
