@@ -59,6 +59,15 @@ struct KParams {
     unsigned char* rgb8;     // 3 bytes per local pixel, or null
     float* radiance;         // 3 floats per local pixel, or null
     unsigned* queue;         // work-item counter (zeroed before each launch)
+    // Fine-grained tail (tail_block < 0: off).  The frame's last sample block is handed out as (pixel, group of
+    // tail_group_spp samples) items that store every sample's radiance separately; the combine pass adds that block's
+    // samples in order, which is bit for bit what a lane summing the block in registers computes.  The launch then runs
+    // dry on 16-sample items instead of 64-sample ones (a 14 ms tail per launch on the benchmark frame otherwise).
+    int tail_block;          // global index of the block handled that way
+    int tail_group_spp;      // samples per tail item
+    int tail_samples_in_block; // samples the tail block holds (the frame's last block may be partial)
+    unsigned tail_first_item; // queue index of the first tail item of this launch
+    float4* tail_samples;    // [pix_items][block_spp] per-sample radiance of the tail block
     unsigned long long* counters; // [0] rays [1] inner-node visits [2] triangle tests [3] plane tests
 };
 

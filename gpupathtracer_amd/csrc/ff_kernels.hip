@@ -1123,7 +1123,10 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
             } else {
                 // an item is one sample block of one pixel; pixels walk 8x8 tiles of the local image (padding items and
                 // untraced pixels are consumed and skipped), blocks are the slow index
-                const unsigned blk = item / p.pix_items, pitem = item - blk * p.pix_items;
+                // items [0, tail_first_item): (pixel, whole block); beyond: (pixel, sample group) of the tail block, group-major
+                const bool tail = p.tail_block >= 0 && item >= p.tail_first_item;
+                const unsigned rel = tail ? item - p.tail_first_item : item;
+                const unsigned blk = rel / p.pix_items, pitem = rel - blk * p.pix_items; // tail: blk is the group index
                 const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
                 const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
                 const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
@@ -1131,11 +1134,18 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                 const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
                 if (lx < p.xlim && ly < p.local_rows && gy < p.ylim) {
                     got = true;
-                    const int block = p.block_begin + (int)blk;
-                    P.bitem = block * (int)p.pix_items + (int)pitem;
                     P.gxy = (unsigned)lx | ((unsigned)gy << 16);
-                    P.s = block * p.block_spp;
-                    P.send = min(p.spp_total, P.s + p.block_spp);
+                    if (tail) {
+                        const int first = (int)blk * p.tail_group_spp; // first sample of the group inside the block
+                        P.bitem = ~((int)pitem * p.block_spp + first); // negative: slot of the next sample in tail_samples
+                        P.s = p.tail_block * p.block_spp + first;
+                        P.send = min(p.spp_total, P.s + p.tail_group_spp);
+                    } else {
+                        const int block = p.block_begin + (int)blk;
+                        P.bitem = block * (int)p.pix_items + (int)pitem;
+                        P.s = block * p.block_spp;
+                        P.send = min(p.spp_total, P.s + p.block_spp);
+                    }
                     P.ax = P.ay = P.az = 0.f;
                     primary_ray(p, P.gxy, P.ray); // once per (pixel, block); its samples reuse the direction
                     P.pdx = P.ray.dx;
@@ -1263,16 +1273,22 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
         }
     }
     if (!path_done) return true;
-    P.ax = P.ax + Lx;
-    P.ay = P.ay + Ly;
-    P.az = P.az + Lz;
+    if (P.bitem < 0) {
+        // tail item: every sample is stored on its own; the combine pass adds the block's samples in order
+        p.tail_samples[~P.bitem] = make_float4(Lx, Ly, Lz, 0.f);
+        --P.bitem; // ~(slot + 1)
+    } else {
+        P.ax = P.ax + Lx;
+        P.ay = P.ay + Ly;
+        P.az = P.az + Lz;
+    }
     ++P.s;
     if (P.s < P.send && !debug_shade) {
         start_sample(p, P);
         return true;
     }
     // sample block finished: its sum goes to the block buffer (the combine kernel adds a pixel's blocks in order)
-    p.blocksums[P.bitem] = make_float4(P.ax, P.ay, P.az, 0.f);
+    if (P.bitem >= 0) p.blocksums[P.bitem] = make_float4(P.ax, P.ay, P.az, 0.f);
     return false;
 }
 
@@ -1703,7 +1719,21 @@ __global__ void combine_kernel(const KParams p)
     const unsigned pitem = (unsigned)(((ly >> 3) * p.tiles_per_row + (lx >> 3)) * 64 + ((ly & 7) * 8 + (lx & 7)));
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (int b = 0; b < p.num_blocks; ++b) {
-        const float4 v = p.blocksums[(size_t)b * p.pix_items + pitem];
+        float4 v;
+        if (b == p.tail_block) {
+            // this block was traced sample by sample: the sequential sum a lane would have kept in registers
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            const float4* sp = p.tail_samples + (size_t)pitem * (size_t)p.block_spp;
+            for (int i = 0; i < p.tail_samples_in_block; ++i) {
+                const float4 l = sp[i];
+                bx = bx + l.x;
+                by = by + l.y;
+                bz = bz + l.z;
+            }
+            v = make_float4(bx, by, bz, 0.f);
+        } else {
+            v = p.blocksums[(size_t)b * p.pix_items + pitem];
+        }
         ax = ax + v.x;
         ay = ay + v.y;
         az = az + v.z;

@@ -277,3 +277,30 @@ def test_lean_ieee_sequences_are_exact_for_every_float(tracer):
     """The kernels replace the IEEE expansions of 1/x and sqrt(x) by one Newton step on the hardware estimates inside
     2^-60..2^60 (full expansion outside): bit-identical for all 2^32 inputs, or the parity claims would not hold."""
     assert tracer.check_ieee() == (0, 0)
+
+
+def test_fine_grained_tail_is_bit_identical(monkeypatch):
+    """From four sample blocks on, the frame's last block is traced as 16-sample items with per-sample storage and summed in
+    order by the combine pass: same bits as the all-in-registers path (FF_TAIL_GROUP=0) and as the oracle, including a
+    partial last block."""
+    scene = scenes.cornell_wahoo_scene()
+    cam = scenes.posed_camera(160, 90, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    out = {}
+    for group in ("0", "32", "16", "8"):
+        monkeypatch.setenv("FF_TAIL_GROUP", group)
+        with lib.Tracer(0) as t:
+            t.upload_scene(scene)
+            for spp in (256, 300, 1024 + 40):
+                out[(group, spp)] = t.render(cam, lib.render_params(160, 90, 5, spp, 77))
+    for spp in (256, 300, 1024 + 40):
+        for group in ("32", "16", "8"):
+            assert np.array_equal(out[(group, spp)][0], out[("0", spp)][0])
+            assert np.array_equal(out[(group, spp)][1].view(np.uint32), out[("0", spp)][1].view(np.uint32)), (group, spp)
+    monkeypatch.delenv("FF_TAIL_GROUP")
+    small = scenes.posed_camera(12, 9, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    p = lib.render_params(12, 9, 4, 300, 5)  # five blocks, the last one holds 44 samples
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        rgb8, rad = t.render(small, p)
+    o_rgb8, o_rad = oracle_render(scene, small, p, threads=16)
+    assert np.array_equal(rgb8, o_rgb8) and np.array_equal(rad.view(np.uint32), o_rad.view(np.uint32))
