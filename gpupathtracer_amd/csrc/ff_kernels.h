@@ -67,7 +67,7 @@ struct KParams {
     int tail_group_spp;      // samples per tail item
     int tail_samples_in_block; // samples the tail block holds (the frame's last block may be partial)
     unsigned tail_first_item; // queue index of the first tail item of this launch
-    float4* tail_samples;    // [pix_items][block_spp] per-sample radiance of the tail block
+    float4* tail_samples;    // [block_spp][pix_items] per-sample radiance of the tail block
     unsigned long long* counters; // [0] rays [1] inner-node visits [2] triangle tests [3] plane tests
 };
 

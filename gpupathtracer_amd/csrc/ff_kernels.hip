@@ -1137,7 +1137,7 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                     P.gxy = (unsigned)lx | ((unsigned)gy << 16);
                     if (tail) {
                         const int first = (int)blk * p.tail_group_spp; // first sample of the group inside the block
-                        P.bitem = ~((int)pitem * p.block_spp + first); // negative: slot of the next sample in tail_samples
+                        P.bitem = ~(first * (int)p.pix_items + (int)pitem); // negative: slot of the next sample in tail_samples (sample-major)
                         P.s = p.tail_block * p.block_spp + first;
                         P.send = min(p.spp_total, P.s + p.tail_group_spp);
                     } else {
@@ -1276,7 +1276,7 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
     if (P.bitem < 0) {
         // tail item: every sample is stored on its own; the combine pass adds the block's samples in order
         p.tail_samples[~P.bitem] = make_float4(Lx, Ly, Lz, 0.f);
-        --P.bitem; // ~(slot + 1)
+        P.bitem -= (int)p.pix_items; // ~(slot + pix_items): the pixel's next sample
     } else {
         P.ax = P.ax + Lx;
         P.ay = P.ay + Ly;
@@ -1723,9 +1723,9 @@ __global__ void combine_kernel(const KParams p)
         if (b == p.tail_block) {
             // this block was traced sample by sample: the sequential sum a lane would have kept in registers
             float bx = 0.f, by = 0.f, bz = 0.f;
-            const float4* sp = p.tail_samples + (size_t)pitem * (size_t)p.block_spp;
+            const float4* sp = p.tail_samples + pitem; // sample-major: neighbouring threads read neighbouring values
             for (int i = 0; i < p.tail_samples_in_block; ++i) {
-                const float4 l = sp[i];
+                const float4 l = sp[(size_t)i * p.pix_items];
                 bx = bx + l.x;
                 by = by + l.y;
                 bz = bz + l.z;
