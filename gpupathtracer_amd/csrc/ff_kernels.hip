@@ -1136,10 +1136,10 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                     got = true;
                     P.gxy = (unsigned)lx | ((unsigned)gy << 16);
                     if (tail) {
-                        const int first = (int)blk * p.tail_group_spp; // first sample of the group inside the block
+                        const int first = p.tail_start[blk], past = p.tail_start[blk + 1]; // the group's samples inside the block
                         P.bitem = ~(first * (int)p.pix_items + (int)pitem); // negative: slot of the next sample in tail_samples (sample-major)
                         P.s = p.tail_block * p.block_spp + first;
-                        P.send = min(p.spp_total, P.s + p.tail_group_spp);
+                        P.send = min(p.spp_total, p.tail_block * p.block_spp + past);
                     } else {
                         const int block = p.block_begin + (int)blk;
                         P.bitem = block * (int)p.pix_items + (int)pitem;

@@ -297,6 +297,15 @@ def test_fine_grained_tail_is_bit_identical(monkeypatch):
             assert np.array_equal(out[(group, spp)][0], out[("0", spp)][0])
             assert np.array_equal(out[(group, spp)][1].view(np.uint32), out[("0", spp)][1].view(np.uint32)), (group, spp)
     monkeypatch.delenv("FF_TAIL_GROUP")
+    # the strips of a multi-GPU rank (their own launches, their own tail) equal the rows of the full frame
+    full = out[("0", 300)][1]
+    p300 = lib.render_params(160, 90, 5, 300, 77)
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        for part in range(3):
+            _, rad = t.render_strips(cam, p300, 4, part, 3)
+            rows = ffdist.strip_row_indices(90, 4, part, 3)
+            assert np.array_equal(rad.view(np.uint32), full[rows].view(np.uint32)), part
     small = scenes.posed_camera(12, 9, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     p = lib.render_params(12, 9, 4, 300, 5)  # five blocks, the last one holds 44 samples
     with lib.Tracer(0) as t:
