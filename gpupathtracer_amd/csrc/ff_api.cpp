@@ -138,11 +138,13 @@ int check_params(const FfRenderParams* p)
 }
 
 // Core of every render entry point.  rgb8_dev / radiance_dev are device pointers to the LOCAL image (local_rows x W).
+// The window [x0, x0 + win_w) x (y0 + the strip layout's rows) of the image; whole-width strips pass x0 = y0 = 0, win_w = width.
 int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, int strip_rows, int part, int num_parts, int local_rows,
-                 unsigned char* rgb8_dev, float* radiance_dev)
+                 unsigned char* rgb8_dev, float* radiance_dev, int x0 = 0, int y0 = 0, int win_w = -1)
 {
     const int W = prm->width, H = prm->height;
-    const size_t local_pixels = (size_t)local_rows * (size_t)W;
+    if (win_w < 0) win_w = W;
+    const size_t local_pixels = (size_t)local_rows * (size_t)win_w;
     s->stats = FfStats();
     if (local_pixels == 0) return FF_OK;
 
@@ -184,7 +186,10 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.part = part;
     k.num_parts = num_parts;
     k.local_rows = local_rows;
-    k.tiles_per_row = (W + 7) / 8;
+    k.x0 = x0;
+    k.y0 = y0;
+    k.local_width = win_w;
+    k.tiles_per_row = (win_w + 7) / 8;
     const uint64_t tiles = (uint64_t)k.tiles_per_row * (uint64_t)((local_rows + 7) / 8);
     if (tiles * 64 * (uint64_t)(num_blocks + 64) >= (1ull << 31)) return fail(FF_ERR_INVALID_ARG, "image too large for the work queue");
     k.pix_items = (unsigned)(tiles * 64);
@@ -784,6 +789,48 @@ int ff_render_strips(FfState* s, const FfCamera* camera, const FfRenderParams* p
     if (st != FF_OK) return st;
     if (rgb8 && !rgb8_on_device && local_pixels) FF_HIP(hipMemcpy(rgb8, rgb8_dev, local_pixels * 3, hipMemcpyDeviceToHost));
     if (radiance && !radiance_on_device && local_pixels) FF_HIP(hipMemcpy(radiance, rad_dev, local_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FF_OK;
+}
+
+int ff_render_tile(FfState* s, const FfCamera* camera, const FfRenderParams* params, int x0, int y0, int w, int h, void* rgb8, int rgb8_on_device,
+                   float* radiance, int radiance_on_device)
+{
+    clear_error();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_tile: state is null");
+    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_tile: camera is null");
+    int st = check_params(params);
+    if (st != FF_OK) return st;
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_tile: no scene uploaded");
+    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
+        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > params->width || y0 + h > params->height)
+        return fail(FF_ERR_INVALID_ARG, "ff_render_tile: tile %dx%d at (%d, %d) is not inside the %dx%d image", w, h, x0, y0, params->width, params->height);
+    FF_HIP(hipSetDevice(s->device));
+    const size_t pixels = (size_t)w * (size_t)h;
+    unsigned char* rgb8_dev = nullptr;
+    float* rad_dev = nullptr;
+    if (rgb8) {
+        if (rgb8_on_device) rgb8_dev = (unsigned char*)rgb8;
+        else {
+            st = ensure_bytes((void**)&s->d_rgb8, &s->rgb8_bytes, pixels * 3 + 16);
+            if (st != FF_OK) return st;
+            rgb8_dev = s->d_rgb8;
+        }
+    }
+    if (radiance) {
+        if (radiance_on_device) rad_dev = radiance;
+        else {
+            st = ensure_bytes((void**)&s->d_radiance, &s->radiance_bytes, pixels * 3 * sizeof(float) + 16);
+            if (st != FF_OK) return st;
+            rad_dev = s->d_radiance;
+        }
+    }
+    st = render_local(s, camera, params, h, 0, 1, h, rgb8_dev, rad_dev, x0, y0, w);
+    if (st != FF_OK) return st;
+    if (rgb8 && !rgb8_on_device) FF_HIP(hipMemcpy(rgb8, rgb8_dev, pixels * 3, hipMemcpyDeviceToHost));
+    if (radiance && !radiance_on_device) FF_HIP(hipMemcpy(radiance, rad_dev, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return FF_OK;
 }

@@ -25,6 +25,8 @@ struct KParams {
     int xlim, ylim;    // pixels with x >= xlim or y >= ylim are not traced (FF_GRID_REFERENCE_FLOOR)
     // work decomposition: local rows of this part, in strips
     int strip_rows, part, num_parts, local_rows;
+    int x0, y0, local_width; // window inside the image: local pixel (lx, ly) is global (x0 + lx, y0 + row of the strip layout);
+                             // whole-width strips: x0 = y0 = 0, local_width = width
     unsigned total_items; // work items of this launch: pix_items x (block_end - block_begin)
     int items_per_fetch;  // items a lane takes per queue fetch (1 for long items; more when an item is only a few samples)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)

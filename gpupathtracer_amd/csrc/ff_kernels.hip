@@ -1131,10 +1131,11 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                 const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
                 const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
                 const int strip = ly / p.strip_rows;
-                const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
-                if (lx < p.xlim && ly < p.local_rows && gy < p.ylim) {
+                const int gy = p.y0 + (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
+                const int gx = p.x0 + lx;
+                if (lx < p.local_width && gx < p.xlim && ly < p.local_rows && gy < p.ylim) {
                     got = true;
-                    P.gxy = (unsigned)lx | ((unsigned)gy << 16);
+                    P.gxy = (unsigned)gx | ((unsigned)gy << 16);
                     if (tail) {
                         const int first = p.tail_start[blk], past = p.tail_start[blk + 1]; // the group's samples inside the block
                         P.bitem = ~(first * (int)p.pix_items + (int)pitem); // negative: slot of the next sample in tail_samples (sample-major)
@@ -1712,10 +1713,10 @@ __global__ void combine_kernel(const KParams p)
 {
     const int lx = blockIdx.x * blockDim.x + threadIdx.x;
     const int ly = blockIdx.y;
-    if (lx >= p.width || ly >= p.local_rows) return;
+    if (lx >= p.local_width || ly >= p.local_rows) return;
     const int strip = ly / p.strip_rows;
-    const int gy = (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
-    if (lx >= p.xlim || gy >= p.ylim) return;
+    const int gy = p.y0 + (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
+    if (p.x0 + lx >= p.xlim || gy >= p.ylim) return;
     const unsigned pitem = (unsigned)(((ly >> 3) * p.tiles_per_row + (lx >> 3)) * 64 + ((ly & 7) * 8 + (lx & 7)));
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (int b = 0; b < p.num_blocks; ++b) {
@@ -1743,7 +1744,7 @@ __global__ void combine_kernel(const KParams p)
         const float inv = 1.0f / (float)p.spp_total;
         rx = ax * inv; ry = ay * inv; rz = az * inv;
     }
-    const size_t lpix = (size_t)ly * (size_t)p.width + (size_t)lx;
+    const size_t lpix = (size_t)ly * (size_t)p.local_width + (size_t)lx;
     if (p.radiance) {
         p.radiance[3 * lpix] = rx;
         p.radiance[3 * lpix + 1] = ry;
@@ -1897,8 +1898,8 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
 
 hipError_t launch_combine(const KParams& p, hipStream_t stream)
 {
-    if (p.width <= 0 || p.local_rows <= 0) return hipSuccess;
-    const dim3 block(256), grid((p.width + 255) / 256, p.local_rows);
+    if (p.local_width <= 0 || p.local_rows <= 0) return hipSuccess;
+    const dim3 block(256), grid((p.local_width + 255) / 256, p.local_rows);
     hipLaunchKernelGGL(combine_kernel, grid, block, 0, stream, p);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libfirefly_hip.so")
 EXPORTS = [
     "ff_create", "ff_destroy", "ff_last_error", "ff_version", "ff_set_stream",
     "ff_geometry_init", "ff_bxdf_init", "ff_camera_init_default", "ff_camera_update_basis", "ff_camera_ray_matrix",
-    "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh",
+    "ff_render_tile", "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh",
     "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
@@ -70,6 +70,7 @@ def load():
     lib.ff_debug_download_bvh.argtypes = [vp, vp, i32, P(i32), vp, i32, P(i32), P(i32), i32]
     lib.ff_scene_info.argtypes = [P(T.FfGeometry), i32, P(T.FfSceneInfo)]
     lib.ff_render.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), vp, i32, vp, i32]
+    lib.ff_render_tile.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, i32, i32, i32, vp, i32, vp, i32]
     lib.ff_render_strips.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, i32, i32, vp, i32, vp, i32, P(i32)]
     lib.ff_strips_local_rows.argtypes = [i32, i32, i32, i32]
     lib.ff_deinterleave_strips.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
@@ -268,6 +269,13 @@ class Tracer:
         rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
         rad = np.zeros((h, w, 3), dtype=np.float32)
         check(self._lib.ff_render_progressive(self._state, C.byref(camera), C.byref(params), frame_index, rgb8.ctypes.data, 0, rad.ctypes.data, 0))
+        return rgb8, rad
+
+    def render_tile(self, camera, params, x0, y0, w, h):
+        """Tile [x0, x0+w) x [y0, y0+h) of the frame -> (rgb8 [h,w,3], radiance [h,w,3])."""
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        rad = np.zeros((h, w, 3), dtype=np.float32)
+        check(self._lib.ff_render_tile(self._state, C.byref(camera), C.byref(params), x0, y0, w, h, rgb8.ctypes.data, 0, rad.ctypes.data, 0))
         return rgb8, rad
 
     def render_device(self, camera, params, rgb8_ptr=None, radiance_ptr=None):

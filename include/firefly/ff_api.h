@@ -143,6 +143,12 @@ FF_API int ff_render_strips(FfState* state, const FfCamera* camera, const FfRend
                             void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device,
                             int* out_local_rows);
 
+/* One rectangular tile [x0, x0 + w) x [y0, y0 + h) of the frame into compact w x h buffers (row stride w): the other way
+ * to partition a frame (SURVEY.md section 8b's ff_render_tile).  Pixels are identical to the same pixels of ff_render:
+ * the random numbers are keyed on the global pixel index. */
+FF_API int ff_render_tile(FfState* state, const FfCamera* camera, const FfRenderParams* params, int x0, int y0, int w, int h, void* rgb8,
+                          int rgb8_on_device, float* radiance, int radiance_on_device);
+
 /* Number of rows ff_render_strips writes for (height, strip_rows, part, num_parts). */
 FF_API int ff_strips_local_rows(int height, int strip_rows, int part, int num_parts);
 

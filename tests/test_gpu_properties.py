@@ -313,3 +313,21 @@ def test_fine_grained_tail_is_bit_identical(monkeypatch):
         rgb8, rad = t.render(small, p)
     o_rgb8, o_rad = oracle_render(scene, small, p, threads=16)
     assert np.array_equal(rgb8, o_rgb8) and np.array_equal(rad.view(np.uint32), o_rad.view(np.uint32))
+
+
+def test_tiles_equal_the_full_frame(tracer):
+    """ff_render_tile: arbitrary rectangles (ragged sizes, image corners) carry the pixels of the full frame, bit for bit,
+    in both shade modes and with enough samples for the fine-grained tail."""
+    scene = scenes.cornell_wahoo_scene()
+    cam = scenes.posed_camera(101, 67, position=(0.2, -0.3, 2.3), yaw=-95.0, pitch=-4.0)
+    tracer.upload_scene(scene)
+    for params in (lib.render_params(101, 67, 4, 3, 9), lib.render_params(101, 67, 3, 260, 9),
+                   lib.render_params(101, 67, 1, 1, 9, T.TRACE_BVH, T.SHADE_NORMAL_DEBUG, T.GRID_FULL, 0)):
+        full8, full = tracer.render(cam, params)
+        for (x0, y0, w, h) in ((0, 0, 101, 67), (0, 0, 17, 9), (84, 58, 17, 9), (33, 20, 40, 31), (100, 66, 1, 1)):
+            rgb8, rad = tracer.render_tile(cam, params, x0, y0, w, h)
+            assert np.array_equal(rgb8, full8[y0:y0 + h, x0:x0 + w]), (x0, y0, w, h)
+            assert np.array_equal(rad.view(np.uint32), full[y0:y0 + h, x0:x0 + w].view(np.uint32)), (x0, y0, w, h)
+    with pytest.raises(lib.FireflyError) as e:
+        tracer.render_tile(cam, lib.render_params(101, 67, 1, 1), 90, 0, 20, 5)
+    assert e.value.status == T.FF_ERR_INVALID_ARG
