@@ -89,10 +89,17 @@ def cpu_baseline(scene, camera, args):
     t0 = time.perf_counter()
     _, _, ctr = oracle_render(scene, camera, params, window=(x0, y0, w, h), threads=threads, want_counters=True)
     dt = time.perf_counter() - t0
+    # one core on a quarter of that window (SURVEY.md section 8d asks for both figures)
+    w1, h1 = w // 2, h // 2
+    t1 = time.perf_counter()
+    _, _, ctr1 = oracle_render(scene, camera, params, window=((args.width - w1) // 2, (args.height - h1) // 2, w1, h1), threads=1, want_counters=True)
+    dt1 = time.perf_counter() - t1
     return {
         "value": round(ctr.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": f"centre {w}x{h} window of the {args.width}x{args.height} frame, {args.bounces} bounces, {spp} spp, "
                   f"brute force over {scene.triangle_count} triangles: {ctr.rays} rays in {dt:.2f} s",
+        "single_core": {"value": round(ctr1.rays / dt1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                        "sample": f"centre {w1}x{h1} window, same frame and parameters: {ctr1.rays} rays in {dt1:.2f} s"},
     }
 
 
