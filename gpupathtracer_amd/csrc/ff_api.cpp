@@ -65,8 +65,9 @@ struct FfState {
     float* d_mean = nullptr;
     size_t mean_bytes = 0;
     int accum_width = 0, accum_height = 0, accum_frames = 0;
-    unsigned* d_queue = nullptr;
-    unsigned long long* d_counters = nullptr;
+    unsigned* d_queue = nullptr;               // work-queue counter: lives right behind the counters (one memset clears both)
+    unsigned long long* d_counters = nullptr;  // 28 counters + 4 queue words
+    unsigned long long* h_counters = nullptr;  // pinned mirror for the per-frame read-back
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
@@ -253,10 +254,13 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
         k.pool_low = s->pool_low;
     }
     hipStream_t st = s->stream;
-    // cudaMemset(pbo, 0) of kernel.cu:340: untraced and missed pixels read 0
-    if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
-    if (radiance_dev) FF_HIP(hipMemsetAsync(radiance_dev, 0, local_pixels * 3 * sizeof(float), st));
-    FF_HIP(hipMemsetAsync(s->d_counters, 0, 28 * sizeof(unsigned long long), st));
+    // cudaMemset(pbo, 0) of kernel.cu:340: untraced pixels read 0.  With the full grid the combine pass writes every pixel
+    // of the window (a missed pixel gets its zero sum), so the clears are only needed for the reference's floor grid.
+    if (prm->grid_mode == FF_GRID_REFERENCE_FLOOR) {
+        if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
+        if (radiance_dev) FF_HIP(hipMemsetAsync(radiance_dev, 0, local_pixels * 3 * sizeof(float), st));
+    }
+    FF_HIP(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), st)); // counters and the work queue behind them
     FF_HIP(hipEventRecord(s->ev_begin, st));
     // Fine-grained tail: in the launch that finishes the frame, the last block (if the launch has at least four) is traced
     // as 16-sample items with per-sample storage (see KParams::tail_samples).
@@ -290,16 +294,17 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
             k.tail_first_item = k.pix_items * (unsigned)(k.block_end - 1 - k.block_begin);
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
-        FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
+        if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
         FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st));
     }
     FF_HIP(launch_combine(k, st));
     FF_HIP(hipEventRecord(s->ev_end, st));
+    FF_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, 28 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     FF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     FF_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
     unsigned long long c[28];
-    FF_HIP(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    std::memcpy(c, s->h_counters, sizeof c);
     std::memcpy(s->raw_counters, c, sizeof c);
     s->stats.rays_traced = c[0];
     s->stats.nodes_visited = c[1];
@@ -348,11 +353,13 @@ int ff_create(FfState** out_state, int device_id)
         delete s;
         return fail(FF_ERR_HIP, "ff_create: kernel preparation failed: %s (is this a gfx950 device?)", hipGetErrorString(pe));
     }
-    if (hipMalloc((void**)&s->d_queue, 64) != hipSuccess || hipMalloc((void**)&s->d_counters, 28 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc((void**)&s->h_counters, 32 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         ff_destroy(s);
         return fail(FF_ERR_HIP, "ff_create: allocating work buffers failed");
     }
+    s->d_queue = reinterpret_cast<unsigned*>(s->d_counters + 28);
     *out_state = s;
     return FF_OK;
 }
@@ -373,8 +380,8 @@ int ff_destroy(FfState* s)
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_rgb8) (void)hipFree(s->d_rgb8);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
-    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->h_counters) (void)hipHostFree(s->h_counters);
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_end) (void)hipEventDestroy(s->ev_end);
     delete s;
