@@ -297,6 +297,12 @@ def test_fine_grained_tail_is_bit_identical(monkeypatch):
             assert np.array_equal(out[(group, spp)][0], out[("0", spp)][0])
             assert np.array_equal(out[(group, spp)][1].view(np.uint32), out[("0", spp)][1].view(np.uint32)), (group, spp)
     monkeypatch.delenv("FF_TAIL_GROUP")
+    # a frame split into several launches (the tail then belongs to the last launch only, if it has four blocks)
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        for per_launch in (64, 128, 600):
+            chunked = t.render(cam, lib.render_params(160, 90, 5, 1024 + 40, 77, spp_per_launch=per_launch))[1]
+            assert np.array_equal(chunked.view(np.uint32), out[("0", 1024 + 40)][1].view(np.uint32)), per_launch
     # the strips of a multi-GPU rank (their own launches, their own tail) equal the rows of the full frame
     full = out[("0", 300)][1]
     p300 = lib.render_params(160, 90, 5, 300, 77)
