@@ -82,6 +82,8 @@ struct FfState {
     // GL interop
     hipGraphicsResource* pbo_resource = nullptr;
     int pbo_width = 0, pbo_height = 0;
+    // fault injection for tests (FF_DEBUG_FAIL_ALLOC=k: the k-th scene allocation of every upload reports out-of-memory)
+    int debug_fail_alloc = -1, alloc_countdown = -1;
 };
 
 namespace {
@@ -89,7 +91,7 @@ namespace {
 #define FF_HIP(call)                                                                                          \
     do {                                                                                                      \
         hipError_t _e = (call);                                                                               \
-        if (_e != hipSuccess) return fail(FF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+        if (_e != hipSuccess) return fail(_e == hipErrorOutOfMemory ? FF_ERR_OOM : FF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
 void free_scene(FfState* s)
@@ -110,6 +112,16 @@ void free_scene(FfState* s)
     s->has_scene = false;
     s->num_geoms = s->num_nodes = s->max_depth = 0;
     s->num_tris = 0;
+}
+
+// hipMalloc for the scene arrays (with the test hook above).
+hipError_t scene_alloc(FfState* s, void** ptr, size_t bytes)
+{
+    if (s->alloc_countdown >= 0 && s->alloc_countdown-- == 0) {
+        *ptr = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(ptr, bytes);
 }
 
 int ensure_bytes(void** ptr, size_t* cap, size_t need)
@@ -136,6 +148,32 @@ int check_params(const FfRenderParams* p)
     if (p->grid_mode != FF_GRID_FULL && p->grid_mode != FF_GRID_REFERENCE_FLOOR) return fail(FF_ERR_INVALID_ARG, "unknown grid_mode %d", p->grid_mode);
     if (p->spp_per_launch < 0) return fail(FF_ERR_INVALID_ARG, "spp_per_launch must be >= 0");
     return FF_OK;
+}
+
+// What every render entry point checks before it touches the device.
+int check_render_call(const FfState* s, const FfCamera* camera, const FfRenderParams* params, const char* who)
+{
+    if (!s) return fail(FF_ERR_INVALID_ARG, "%s: state is null", who);
+    if (!camera) return fail(FF_ERR_INVALID_ARG, "%s: camera is null", who);
+    const int st = check_params(params);
+    if (st != FF_OK) return st;
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "%s: no scene uploaded", who);
+    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
+        return fail(FF_ERR_UNSUPPORTED, "%s: BVH mode supports at most %d geometries (scene has %d)", who, kMaxGeometriesBvh, s->num_geoms);
+    return FF_OK;
+}
+
+// Workgroup size of the BVH kernel for the uploaded scene: the preferred size if the lane-strided traversal stacks
+// (4 bytes x workgroup size per tree level) and the geometry records fit the 160 KiB of LDS, else the largest smaller
+// instantiation that does; 0 if even 512 threads do not fit (a degenerate, chain-like device-built tree).
+int bvh_block_threads(const FfState* s, int preferred)
+{
+    const int sizes[3] = { 1024, 768, 512 };
+    for (int b : sizes) {
+        if (b > preferred) continue;
+        if (bvh_lds_bytes(0, s->max_depth + 1, b, s->num_geoms) <= (size_t)kLdsBudgetBytes) return b;
+    }
+    return 0;
 }
 
 // Core of every render entry point.  rgb8_dev / radiance_dev are device pointers to the LOCAL image (local_rows x W).
@@ -224,10 +262,16 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     k.tris = s->d_tris;
     k.trinormals = prm->shade_mode == FF_SHADE_DIFFUSE_PATH_SMOOTH ? reinterpret_cast<const float4*>(s->d_normals) : nullptr;
     k.nodes = s->d_nodes;
-    const int block_threads = prm->trace_mode == FF_TRACE_BVH ? s->block_threads : kBlockThreads;
+    int block_threads = kBlockThreads;
+    if (prm->trace_mode == FF_TRACE_BVH) {
+        block_threads = bvh_block_threads(s, s->block_threads);
+        if (block_threads == 0)
+            return fail(FF_ERR_UNSUPPORTED, "BVH of depth %d does not fit the LDS traversal stack (512 threads x %d levels + %d geometry records > 160 KiB); "
+                        "upload with FF_BUILD_HOST_SAH (depth <= 30) or render with FF_TRACE_BRUTE_FORCE", s->max_depth, s->max_depth + 1, s->num_geoms);
+    }
     k.stack_depth = s->max_depth + 1; // at most one pending sibling per level above the cursor, plus one spare slot
     // (the experimental pool scheduler handles single-chunk scenes only)
-    const bool use_pool = prm->trace_mode == FF_TRACE_BVH && s->scheduler == 1 && s->num_geoms <= 32;
+    const bool use_pool = prm->trace_mode == FF_TRACE_BVH && s->scheduler == 1 && s->num_geoms <= 32 && block_threads == 1024;
     int fit = max_lds_nodes(k.stack_depth, use_pool ? 1024 : block_threads, s->num_geoms);
     if (use_pool) fit -= (int)((pool_list_bytes(s->pool_slots, 1024) + sizeof(BvhNode) - 1) / sizeof(BvhNode));
     k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;
@@ -341,6 +385,7 @@ int ff_create(FfState** out_state, int device_id)
         const int v = std::atoi(bt);
         if (v == 512 || v == 768 || v == 1024) s->block_threads = v;
     }
+    if (const char* e = std::getenv("FF_DEBUG_FAIL_ALLOC")) s->debug_fail_alloc = std::atoi(e);
     if (const char* e = std::getenv("FF_TAIL_GROUP")) s->tail_group_spp = std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) s->setup_threshold = std::max(0, std::min(1 << 14, std::atoi(e)));
     if (const char* e = std::getenv("FF_SCHEDULER")) s->scheduler = std::strcmp(e, "pool") == 0 ? 1 : 0;
@@ -474,14 +519,15 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     if (st != FF_OK) return st;
     FF_HIP(hipSetDevice(s->device));
     free_scene(s);
+    s->alloc_countdown = s->debug_fail_alloc;
     const int device_leaf = device_leaf_tris(bp);
     size_t node_cap = 0;
     for (const GeomRecord& g : cs.geoms)
         if (g.type == FF_GEOM_TRIANGLEMESH && g.tri_count > 0) node_cap += gpu_build_max_nodes(g.tri_count);
-    FF_HIP(hipMalloc((void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
-    FF_HIP(hipMalloc((void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
-    FF_HIP(hipMalloc((void**)&s->d_normals, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriNormals)));
-    FF_HIP(hipMalloc((void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_normals, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriNormals)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
     s->node_capacity = node_cap;
     s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
     int node_base = 0;
@@ -530,6 +576,10 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
 
 } // namespace
 
+namespace {
+int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, const BvhBuildParams& bp);
+}
+
 int ff_set_builder(FfState* s, int builder)
 {
     clear_error();
@@ -552,6 +602,18 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
         if (st != FF_OK) free_scene(s);
         return st;
     }
+    const int st = upload_host_built(s, host_geometries, n, bp);
+    if (st != FF_OK) free_scene(s); // never leave a half-allocated scene behind (has_scene is false again)
+    s->build_stats.total_ms = ms_since(t_call);
+    return st;
+}
+
+} // extern "C"
+
+namespace {
+
+int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, const BvhBuildParams& bp)
+{
     CompiledScene cs;
     const auto t_build = std::chrono::steady_clock::now();
     int st = compile_scene(host_geometries, n, bp, cs);
@@ -559,18 +621,19 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     s->build_stats.build_ms = ms_since(t_build);
     FF_HIP(hipSetDevice(s->device));
     free_scene(s);
+    s->alloc_countdown = s->debug_fail_alloc;
     const auto t_copy = std::chrono::steady_clock::now();
     // One allocation + one copy per array (the reference issues a cudaMallocManaged + two cudaMemcpy per geometry, kernel.cu:277-298).
-    FF_HIP(hipMalloc((void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
     FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
     // Keep the triangle / node arrays non-null so the kernels can form addresses even for plane-only scenes.
     const size_t tri_bytes = (cs.tris.size() ? cs.tris.size() : 1) * sizeof(TriRecord);
     const size_t node_bytes = (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(BvhNode);
-    FF_HIP(hipMalloc((void**)&s->d_tris, tri_bytes));
-    FF_HIP(hipMalloc((void**)&s->d_normals, tri_bytes));
+    FF_HIP(scene_alloc(s, (void**)&s->d_tris, tri_bytes));
+    FF_HIP(scene_alloc(s, (void**)&s->d_normals, tri_bytes));
     static_assert(sizeof(TriNormals) == sizeof(TriRecord), "parallel arrays of equal stride");
     if (!cs.normals.empty()) FF_HIP(hipMemcpy(s->d_normals, cs.normals.data(), cs.normals.size() * sizeof(TriNormals), hipMemcpyHostToDevice));
-    FF_HIP(hipMalloc((void**)&s->d_nodes, node_bytes));
+    FF_HIP(scene_alloc(s, (void**)&s->d_nodes, node_bytes));
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     s->build_stats.copy_ms = ms_since(t_copy);
@@ -608,9 +671,12 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
     s->build_stats.bvh_nodes = s->num_nodes;
     s->build_stats.bvh_max_depth = s->max_depth;
     s->has_scene = true;
-    s->build_stats.total_ms = ms_since(t_call);
     return FF_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
 {
@@ -669,13 +735,19 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
         if (count <= device_leaf_tris(bp)) {
             st = place_single_leaf_mesh(s, triangles, count, bp, rec.tri_first, slot.node_first, &slot.node_count, &slot.depth);
         } else {
-            MeshBuildInfo info;
+            MeshBuildInfo info = MeshBuildInfo();
             st = gpu_build_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, device_leaf_tris(bp), s->d_tris, s->d_normals, s->d_nodes, &info,
                                 s->scene_builder == FF_BUILD_GPU_PLOC);
-            slot.node_count = info.node_count;
-            slot.depth = info.depth;
+            if (st == FF_OK) {
+                slot.node_count = info.node_count;
+                slot.depth = info.depth;
+            }
         }
-        if (st != FF_OK) return st;
+        if (st != FF_OK) {
+            // the mesh's records and nodes may be half rewritten: nothing may render from them
+            s->has_scene = false;
+            return st;
+        }
         slot.parents_linked = false;
         bs.last_operation = 2;
     } else {
@@ -761,13 +833,8 @@ int ff_render_strips(FfState* s, const FfCamera* camera, const FfRenderParams* p
 {
     clear_error();
     const auto t0 = std::chrono::steady_clock::now();
-    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render: state is null");
-    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render: camera is null");
-    int st = check_params(params);
+    int st = check_render_call(s, camera, params, "ff_render");
     if (st != FF_OK) return st;
-    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render: no scene uploaded");
-    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
-        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (strip_rows <= 0 || num_parts <= 0 || part < 0 || part >= num_parts) return fail(FF_ERR_INVALID_ARG, "ff_render_strips: bad strip partition (%d rows, part %d of %d)", strip_rows, part, num_parts);
     FF_HIP(hipSetDevice(s->device));
     const int local_rows = ff_strips_local_rows(params->height, strip_rows, part, num_parts);
@@ -805,13 +872,8 @@ int ff_render_tile(FfState* s, const FfCamera* camera, const FfRenderParams* par
 {
     clear_error();
     const auto t0 = std::chrono::steady_clock::now();
-    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_tile: state is null");
-    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_tile: camera is null");
-    int st = check_params(params);
+    int st = check_render_call(s, camera, params, "ff_render_tile");
     if (st != FF_OK) return st;
-    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_tile: no scene uploaded");
-    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
-        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > params->width || y0 + h > params->height)
         return fail(FF_ERR_INVALID_ARG, "ff_render_tile: tile %dx%d at (%d, %d) is not inside the %dx%d image", w, h, x0, y0, params->width, params->height);
     FF_HIP(hipSetDevice(s->device));
@@ -870,6 +932,8 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     if (trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
         return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (n == 0) return FF_OK;
+    if (trace_mode == FF_TRACE_BVH && bvh_block_threads(s, kBlockThreads) == 0)
+        return fail(FF_ERR_UNSUPPORTED, "ff_intersect_rays: BVH of depth %d does not fit the LDS traversal stack; use FF_TRACE_BRUTE_FORCE or a host-built tree", s->max_depth);
     FF_HIP(hipSetDevice(s->device));
     FfRay* d_rays = nullptr;
     FfIntersect* d_out = nullptr;
@@ -943,14 +1007,11 @@ int ff_render_to_pbo(FfState* s, const FfCamera* camera, const FfRenderParams* p
 {
     clear_error();
     const auto t0 = std::chrono::steady_clock::now();
-    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo: state is null");
-    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo: camera is null");
-    int st = check_params(params);
+    if (s && !s->pbo_resource) return fail(FF_ERR_GL_UNAVAILABLE, "ff_render_to_pbo: no pixel buffer registered");
+    int st = check_render_call(s, camera, params, "ff_render_to_pbo");
     if (st != FF_OK) return st;
-    if (!s->pbo_resource) return fail(FF_ERR_GL_UNAVAILABLE, "ff_render_to_pbo: no pixel buffer registered");
     if (params->width != s->pbo_width || params->height != s->pbo_height)
         return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo: params are %dx%d but the registered buffer is %dx%d", params->width, params->height, s->pbo_width, s->pbo_height);
-    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_to_pbo: no scene uploaded");
     FF_HIP(hipSetDevice(s->device));
     // kernel.cu:335-344
     void* dptr = nullptr;
@@ -1005,13 +1066,8 @@ int ff_render_progressive(FfState* s, const FfCamera* camera, const FfRenderPara
 {
     clear_error();
     const auto t0 = std::chrono::steady_clock::now();
-    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_progressive: state is null");
-    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_progressive: camera is null");
-    int st = check_params(params);
+    int st = check_render_call(s, camera, params, "ff_render_progressive");
     if (st != FF_OK) return st;
-    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_progressive: no scene uploaded");
-    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
-        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     FF_HIP(hipSetDevice(s->device));
     const size_t pixels = (size_t)params->width * (size_t)params->height;
     unsigned char* rgb8_dev = nullptr;
@@ -1044,15 +1100,12 @@ int ff_render_to_pbo_progressive(FfState* s, const FfCamera* camera, const FfRen
 {
     clear_error();
     const auto t0 = std::chrono::steady_clock::now();
-    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo_progressive: state is null");
-    if (!camera) return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo_progressive: camera is null");
-    int st = check_params(params);
+    if (s && !s->pbo_resource) return fail(FF_ERR_GL_UNAVAILABLE, "ff_render_to_pbo_progressive: no pixel buffer registered");
+    int st = check_render_call(s, camera, params, "ff_render_to_pbo_progressive");
     if (st != FF_OK) return st;
-    if (!s->pbo_resource) return fail(FF_ERR_GL_UNAVAILABLE, "ff_render_to_pbo_progressive: no pixel buffer registered");
     if (params->width != s->pbo_width || params->height != s->pbo_height)
         return fail(FF_ERR_INVALID_ARG, "ff_render_to_pbo_progressive: params are %dx%d but the registered buffer is %dx%d", params->width, params->height,
                     s->pbo_width, s->pbo_height);
-    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_render_to_pbo_progressive: no scene uploaded");
     FF_HIP(hipSetDevice(s->device));
     void* dptr = nullptr;
     size_t nbytes = 0;
