@@ -24,6 +24,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NODE_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 24  # algorithmic bytes per BVH node visit / triangle test / ray
+# VALU issue roof (same guide, "Wave scheduling" + cycle constants): 256 CUs x 4 SIMDs, one wave64 VALU instruction per
+# 2 cycles per SIMD, 2.4 GHz -> 1228.8 G wave-instructions/s
+SIMDS, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0
+VALU_PEAK_GINST = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
 
 
 def parse_args():
@@ -42,6 +46,7 @@ def parse_args():
     ap.add_argument("--trace-mode", choices=["bvh", "brute"], default="bvh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp-per-launch", type=int, default=0)
+    ap.add_argument("--no-companion", action="store_true", help="skip the untimed default-camera frame")
     return ap.parse_args()
 
 
@@ -55,24 +60,39 @@ def algorithmic_bytes(st, width, rows, spp):
     return st.rays_traced * RAY_BYTES + st.nodes_visited * NODE_BYTES + st.tris_tested * TRI_BYTES + fb
 
 
-def measured_traffic(args, world):
-    """HBM bytes per launch of the dominant kernel from the committed PMC measurement (profiles/*_traffic.json, collected
-    with rocprofv3 --pmc in separate passes), when it was taken on exactly this workload; otherwise None."""
+def measured_pmc(args, world, kernel):
+    """The committed PMC measurement of the dominant kernel (profiles/*_pmc.json: rocprofv3 --pmc, separate passes,
+    tools/pmc_passes.sh + tools/pmc_to_json.py) taken on exactly this workload and kernel instantiation; the newest one
+    wins; None if there is none."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if not name.endswith("_traffic.json"):
+        if not name.endswith("_pmc.json"):
             continue
         try:
             with open(os.path.join(pdir, name)) as f:
                 d = json.load(f)
             w = d["workload"]
             if (w["width"], w["height"], w["bounces"], w["spp"], w["n_gpus"], w["camera"], w["trace"]) == (
-                    args.width, args.height, args.bounces, args.spp, world, args.camera, args.trace_mode):
-                best = int(d["hbm_bytes_per_launch"])
+                    args.width, args.height, args.bounces, args.spp, world, args.camera, args.trace_mode) and \
+                    d["kernel"].replace(" ", "") == kernel.replace(" ", ""):
+                best = dict(d, file="profiles/" + name)
         except (OSError, KeyError, ValueError):
             continue
     return best
+
+
+def host_cores():
+    """Cores this process may use: the affinity mask, capped by the cgroup's CPU quota where one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(scene, camera, args):
@@ -82,13 +102,17 @@ def cpu_baseline(scene, camera, args):
     from oracle_lib import oracle_render
     from gpupathtracer_amd import lib
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = host_cores()  # all host cores this process may use
     w, h, spp = 192, 108, 4
     x0, y0 = (args.width - w) // 2, (args.height - h) // 2
     params = lib.render_params(args.width, args.height, args.bounces, spp, args.seed)
-    t0 = time.perf_counter()
-    _, _, ctr = oracle_render(scene, camera, params, window=(x0, y0, w, h), threads=threads, want_counters=True)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, ctr = oracle_render(scene, camera, params, window=(x0, y0, w, h), threads=threads, want_counters=True)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    dt = times[1]  # median of three
     # one core on a quarter of that window (SURVEY.md section 8d asks for both figures)
     w1, h1 = w // 2, h // 2
     t1 = time.perf_counter()
@@ -97,7 +121,8 @@ def cpu_baseline(scene, camera, args):
     return {
         "value": round(ctr.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": f"centre {w}x{h} window of the {args.width}x{args.height} frame, {args.bounces} bounces, {spp} spp, "
-                  f"brute force over {scene.triangle_count} triangles: {ctr.rays} rays in {dt:.2f} s",
+                  f"brute force over {scene.triangle_count} triangles: {ctr.rays} rays in {dt:.2f} s (median of 3; min {times[0]:.2f} s)",
+        "best": round(ctr.rays / times[0] / 1e6, 4),
         "single_core": {"value": round(ctr1.rays / dt1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
                         "sample": f"centre {w1}x{h1} window, same frame and parameters: {ctr1.rays} rays in {dt1:.2f} s"},
     }
@@ -149,17 +174,42 @@ def main():
     tracer.upload_scene(scene)
     tracer.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    strip_rows = ffdist.strip_rows_for(world) if world > 1 else args.height
+    strip_rows = lib.dist_strip_rows(world) if world > 1 else args.height
     local_rows = tracer.strips_local_rows(args.height, strip_rows, rank, world)
-    rgb8 = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.uint8, device=device)
-    rad = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.float32, device=device)
-    full_rgb8 = torch.empty((args.height, args.width, 3), dtype=torch.uint8, device=device) if rank == 0 and world > 1 else None
-    full_rad = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 and world > 1 else None
+    # N > 1: every rank renders its strips, rank 0 gathers them behind the C ABI (ff_render_distributed: packed strips, one
+    # grouped ncclSend / ncclRecv over RCCL, one scatter kernel).  torch.distributed only carries the 128-byte RCCL id here.
+    gather = "none"
+    if world > 1 and backend == "nccl":
+        try:
+            box = [lib.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            tracer.dist_init(rank, world, box[0])
+            gather = "native-rccl"
+        except Exception as e:  # noqa: BLE001 - any failure here must not lose the run: fall back to torch's RCCL gather
+            print(f"[bench] rank {rank}: native RCCL gather unavailable ({e}); using torch.distributed.gather", file=sys.stderr, flush=True)
+            gather = "torch-rccl"
+        ok = torch.tensor([1 if gather == "native-rccl" else 0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gather = "native-rccl" if int(ok.item()) == 1 else "torch-rccl"
+    elif world > 1:
+        gather = "torch-" + backend
+    rgb8 = rad = None
+    if gather != "native-rccl":
+        rgb8 = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.uint8, device=device)
+        rad = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.float32, device=device)
+    full_rgb8 = torch.empty((args.height, args.width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
+    full_rad = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
+    torch.cuda.synchronize()
 
-    def step():
-        tracer.render_strips_device(camera, params, strip_rows, rank, world, rgb8.data_ptr(), rad.data_ptr())
-        if world > 1:
-            # framebuffer gather over RCCL/xGMI to the rank that owns the display buffer, then strip de-interleave
+    def step(cam=None):
+        cam = camera if cam is None else cam
+        if world == 1:
+            tracer.render_device(cam, params, full_rgb8.data_ptr(), full_rad.data_ptr())
+        elif gather == "native-rccl":
+            tracer.render_distributed_device(cam, params, strip_rows, full_rgb8.data_ptr() if rank == 0 else None,
+                                             full_rad.data_ptr() if rank == 0 else None)
+        else:
+            tracer.render_strips_device(cam, params, strip_rows, rank, world, rgb8.data_ptr(), rad.data_ptr())
             if backend == "nccl":
                 g8 = ffdist.gather_strips(rgb8[:local_rows], args.height, strip_rows, rank, world, dist)
                 gr = ffdist.gather_strips(rad[:local_rows], args.height, strip_rows, rank, world, dist)
@@ -186,53 +236,95 @@ def main():
     rays = 0
     kernel_ms = 0.0
     launches = 0
+    frame_ms = []
     for _ in range(args.steps):
+        tf = time.perf_counter()
         st = step()
+        frame_ms.append((time.perf_counter() - tf) * 1e3)
         rays += st.rays_traced
         kernel_ms += st.kernel_ms
         launches += st.kernel_launches
     barrier_sync()
     elapsed = time.perf_counter() - t0
+    kernel = tracer.kernel_name()
 
     if world > 1:
         red_dev = device if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float(rays), kernel_ms, float(counted.rays_traced), float(counted.nodes_visited), float(counted.tris_tested)],
-                           dtype=torch.float64, device=red_dev)
+        agg = torch.tensor([float(rays)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         total_rays = agg[0].item()
     else:
         total_rays = float(rays)
 
+    # ---- companion figure (untimed region, N = 1 only): the same frame from the reference's default camera ----
+    companion = None
+    if world == 1 and args.camera == "inside" and not args.no_companion:
+        dcam = scenes.default_camera(args.width, args.height)
+        step(dcam)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        st2 = step(dcam)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - tc
+        companion = {"camera": "default (kernel.cu:312-321: 12.5 units outside the box, ~96 % primary misses)",
+                     "value": round(st2.rays_traced / dtc / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dtc * 1e3, 3),
+                     "rays_per_frame": int(st2.rays_traced), "frames": 1}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays / elapsed / 1e6
-        # roofline of the dominant kernel (trace_kernel) on this rank: algorithmic bytes per launch / mean launch duration
-        algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, args.spp) / max(1, counted.kernel_launches)
+        # The dominant kernel on this rank: mean launch duration from the HIP events the library records on its launch stream.
         mean_launch_s = kernel_ms / max(1, launches) / 1e3
-        achieved = algo_bytes_launch / mean_launch_s / 1e9
+        rays_per_launch = rays / max(1, launches)
+        algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, args.spp) / max(1, counted.kernel_launches)
+        pmc = measured_pmc(args, world, kernel)
+        roof = {
+            # What binds this kernel is VALU issue at partial lane occupancy, not HBM: the scene is
+            # LDS/L2 resident.  achieved = wave-level VALU instructions per second, from the committed PMC count per ray of
+            # this kernel instantiation on this workload x the rays and the launch duration measured live in this run.
+            "bound": "valu_issue", "unit": "G wave-inst/s", "peak": round(VALU_PEAK_GINST, 1),
+            "kernel": kernel, "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3), "rays_per_launch": int(rays_per_launch),
+            "algorithmic_bytes_per_launch": int(algo_bytes_launch),
+            "algorithmic_GBps": round(algo_bytes_launch / mean_launch_s / 1e9, 1),
+            "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
+                        "tris": round(counted.tris_tested / max(1, counted.rays_traced), 3)},
+        }
+        if pmc is not None:
+            achieved = pmc["valu_insts_per_ray"] * rays_per_launch / mean_launch_s / 1e9
+            traffic = pmc["hbm_bytes_per_ray"] * rays_per_launch
+            roof.update({
+                "achieved": round(achieved, 1), "frac": round(achieved / VALU_PEAK_GINST, 4),
+                "lane_occupancy": pmc["lane_occupancy"], "fp32_lane_throughput_frac": round(achieved / VALU_PEAK_GINST * pmc["lane_occupancy"], 4),
+                "traffic": int(traffic), "hbm_GBps": round(traffic / mean_launch_s / 1e9, 2),
+                "hbm_frac": round(traffic / mean_launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                "algorithmic_vs_hbm": round(algo_bytes_launch / max(traffic, 1.0), 1),
+                "pmc_source": pmc["file"],
+                "note": "algorithmic bytes (SURVEY.md section 8d: 24/ray + 64/node visit + 48/triangle test + framebuffer) are served by LDS and L2; "
+                        "`traffic` is what reaches HBM (FETCH_SIZE x2 + WRITE_SIZE from the PMC passes, scaled by rays)",
+            })
+        else:
+            roof.update({"achieved": None, "frac": None, "traffic": None,
+                         "note": "no committed PMC measurement (profiles/*_pmc.json) matches this workload and kernel instantiation"})
+        frame_ms.sort()
         out = {
             "metric": "Mrays/s (path segments = closest-hit queries, device-counted) at 1080p, 8 bounces, 1024 spp",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "frames_per_s": round(1e3 / ms_per_step, 4),
+            "ms_per_frame_min": round(frame_ms[0], 3), "ms_per_frame_median": round(frame_ms[len(frame_ms) // 2], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"C2 wahoo.obj+cube.obj Cornell box (5184 triangles, 6 planes), {args.width}x{args.height}, "
                             f"{args.bounces} bounces, {args.spp} spp, camera={args.camera}, trace={args.trace_mode}, seed {args.seed}",
                 "rays_per_frame": int(total_rays / args.steps), "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
+                "gather": gather,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, world),
-                "kernel": "trace_bvh_kernel<false,1024,false>", "kernel_ms_per_launch": round(mean_launch_s * 1e3, 3),
-                "algorithmic_bytes_per_launch": int(algo_bytes_launch),
-                "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
-                            "tris": round(counted.tris_tested / max(1, counted.rays_traced), 3)},
-                "note": "algorithmic bytes are served from LDS/L1/L2 (scene = 0.4 MB); HBM traffic is in profiles/ (PMC)",
-            },
+            "roofline": roof,
         }
+        if companion is not None:
+            out["default_camera"] = companion
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, camera, args)
         print(json.dumps(out), flush=True)

@@ -12,87 +12,11 @@
 // (the interop header relies on hip_runtime.h having been included first)
 #include <hip/hip_gl_interop.h>
 
-#include "ff_build.h"
-#include "ff_internal.h"
-#include "ff_kernels.h"
+#include "ff_state.h"
 
 using namespace ff;
 
-struct FfState {
-    int device = 0;
-    int num_cus = 0;
-    hipStream_t stream = nullptr;
-    // scene (device)
-    GeomRecord* d_geoms = nullptr;
-    TriRecord* d_tris = nullptr;
-    TriNormals* d_normals = nullptr; // vertex normals, parallel to d_tris
-    BvhNode* d_nodes = nullptr;
-    int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
-    bool has_specular = false;
-    uint64_t num_tris = 0;
-    bool has_scene = false;
-    // scene bookkeeping for updates (ff_update_transforms / ff_update_mesh)
-    struct MeshSlot {
-        int node_first = 0, node_count = 0, node_capacity = 0, depth = 0;
-        bool parents_linked = false;
-    };
-    int builder = FF_BUILD_HOST_SAH;       // builder for the next upload (ff_set_builder)
-    int scene_builder = FF_BUILD_HOST_SAH; // builder that produced the scene on the device
-    std::vector<GeomRecord> h_geoms;       // the uploaded records, processing order
-    std::vector<MeshSlot> slots;           // parallel to h_geoms (meshes only)
-    size_t node_capacity = 0;              // nodes allocated in d_nodes
-    int* d_parent = nullptr;               // node_capacity ints (refit)
-    FfTriangle* d_stage = nullptr;         // staging copy of a caller triangle array (device builder / refit)
-    size_t stage_bytes = 0;
-    BuildScratch scratch;
-    FfBuildStats build_stats = {};
-    // work buffers (device)
-    float* d_blocksums = nullptr;
-    size_t blocksums_bytes = 0;
-    unsigned char* d_rgb8 = nullptr;
-    size_t rgb8_bytes = 0;
-    float* d_radiance = nullptr;
-    size_t radiance_bytes = 0;
-    // fine-grained tail (KParams::tail_samples)
-    float4* d_tail_samples = nullptr;
-    size_t tail_samples_bytes = 0;
-    int tail_group_spp = 32; // FF_TAIL_GROUP (0 = off); 32 measured best: 8 ranks +3.3 %, 1 rank +0.2 % (16: +3 % / -1.1 %, 8: +3 % / -5 %)
-    // progressive accumulation (ff_render_progressive)
-    float* d_accum = nullptr;
-    size_t accum_bytes = 0;
-    float* d_frame = nullptr;
-    size_t frame_bytes = 0;
-    float* d_mean = nullptr;
-    size_t mean_bytes = 0;
-    int accum_width = 0, accum_height = 0, accum_frames = 0;
-    unsigned* d_queue = nullptr;               // work-queue counter: lives right behind the counters (one memset clears both)
-    unsigned long long* d_counters = nullptr;  // 28 counters + 4 queue words
-    unsigned long long* h_counters = nullptr;  // pinned mirror for the per-frame read-back
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    bool collect_stats = false;
-    int block_threads = kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
-    int scheduler = 0;      // 0 = time-sliced kernel, 1 = path-pool kernel (FF_SCHEDULER=pool)
-    int pool_slots = 192, pool_refill = 16, pool_low = 24;
-    unsigned* d_pool = nullptr;
-    size_t pool_bytes = 0;
-    int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
-                                                   // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
-    FfStats stats;
-    unsigned long long raw_counters[28] = {};
-    // GL interop
-    hipGraphicsResource* pbo_resource = nullptr;
-    int pbo_width = 0, pbo_height = 0;
-    // fault injection for tests (FF_DEBUG_FAIL_ALLOC=k: the k-th scene allocation of every upload reports out-of-memory)
-    int debug_fail_alloc = -1, alloc_countdown = -1;
-};
-
 namespace {
-
-#define FF_HIP(call)                                                                                          \
-    do {                                                                                                      \
-        hipError_t _e = (call);                                                                               \
-        if (_e != hipSuccess) return fail(_e == hipErrorOutOfMemory ? FF_ERR_OOM : FF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
 
 void free_scene(FfState* s)
 {
@@ -124,6 +48,10 @@ hipError_t scene_alloc(FfState* s, void** ptr, size_t bytes)
     return hipMalloc(ptr, bytes);
 }
 
+} // namespace
+
+namespace ff {
+
 int ensure_bytes(void** ptr, size_t* cap, size_t need)
 {
     if (*cap >= need && *ptr) return FF_OK;
@@ -135,6 +63,10 @@ int ensure_bytes(void** ptr, size_t* cap, size_t need)
     *cap = need;
     return FF_OK;
 }
+
+} // namespace ff
+
+namespace {
 
 int check_params(const FfRenderParams* p)
 {
@@ -150,7 +82,10 @@ int check_params(const FfRenderParams* p)
     return FF_OK;
 }
 
-// What every render entry point checks before it touches the device.
+} // namespace
+
+namespace ff {
+
 int check_render_call(const FfState* s, const FfCamera* camera, const FfRenderParams* params, const char* who)
 {
     if (!s) return fail(FF_ERR_INVALID_ARG, "%s: state is null", who);
@@ -162,6 +97,10 @@ int check_render_call(const FfState* s, const FfCamera* camera, const FfRenderPa
         return fail(FF_ERR_UNSUPPORTED, "%s: BVH mode supports at most %d geometries (scene has %d)", who, kMaxGeometriesBvh, s->num_geoms);
     return FF_OK;
 }
+
+} // namespace ff
+
+namespace {
 
 // Workgroup size of the BVH kernel for the uploaded scene: the preferred size if the lane-strided traversal stacks
 // (4 bytes x workgroup size per tree level) and the geometry records fit the 160 KiB of LDS, else the largest smaller
@@ -176,15 +115,19 @@ int bvh_block_threads(const FfState* s, int preferred)
     return 0;
 }
 
-// Core of every render entry point.  rgb8_dev / radiance_dev are device pointers to the LOCAL image (local_rows x W).
-// The window [x0, x0 + win_w) x (y0 + the strip layout's rows) of the image; whole-width strips pass x0 = y0 = 0, win_w = width.
-int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, int strip_rows, int part, int num_parts, int local_rows,
-                 unsigned char* rgb8_dev, float* radiance_dev, int x0 = 0, int y0 = 0, int win_w = -1)
+} // namespace
+
+namespace ff {
+
+// Core of every render entry point (declared in ff_state.h).
+int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm, int strip_rows, int part, int num_parts, int local_rows,
+                   unsigned char* rgb8_dev, float* radiance_dev, int x0, int y0, int win_w)
 {
     const int W = prm->width, H = prm->height;
     if (win_w < 0) win_w = W;
     const size_t local_pixels = (size_t)local_rows * (size_t)win_w;
     s->stats = FfStats();
+    s->pending = false;
     if (local_pixels == 0) return FF_OK;
 
     const bool debug = prm->shade_mode == FF_SHADE_NORMAL_DEBUG;
@@ -339,12 +282,21 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
         if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
-        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st));
+        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st, &s->last_kernel_name));
     }
     FF_HIP(launch_combine(k, st));
     FF_HIP(hipEventRecord(s->ev_end, st));
     FF_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, 28 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    FF_HIP(hipStreamSynchronize(st));
+    s->pending = true;
+    s->pending_launches = launches;
+    return FF_OK;
+}
+
+int render_finish(FfState* s)
+{
+    if (!s->pending) return FF_OK; // nothing was enqueued (an empty part)
+    s->pending = false;
+    FF_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     FF_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
     unsigned long long c[28];
@@ -355,10 +307,22 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
     s->stats.tris_tested = c[2];
     s->stats.planes_tested = c[3];
     s->stats.kernel_ms = ms;
-    s->stats.kernel_launches = (uint32_t)launches;
+    s->stats.kernel_launches = (uint32_t)s->pending_launches;
     s->stats.scene_bytes_nodes = (uint64_t)s->num_nodes * sizeof(BvhNode);
     s->stats.scene_bytes_tris = s->num_tris * sizeof(TriRecord);
     return FF_OK;
+}
+
+} // namespace ff
+
+namespace {
+
+int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, int strip_rows, int part, int num_parts, int local_rows,
+                 unsigned char* rgb8_dev, float* radiance_dev, int x0 = 0, int y0 = 0, int win_w = -1)
+{
+    const int st = render_enqueue(s, camera, prm, strip_rows, part, num_parts, local_rows, rgb8_dev, radiance_dev, x0, y0, win_w);
+    if (st != FF_OK) return st;
+    return render_finish(s);
 }
 
 } // namespace
@@ -414,6 +378,7 @@ int ff_destroy(FfState* s)
     if (!s) return FF_OK;
     (void)hipSetDevice(s->device);
     if (s->pbo_resource) (void)hipGraphicsUnregisterResource(s->pbo_resource);
+    dist_release(s);
     free_scene(s);
     if (s->d_stage) (void)hipFree(s->d_stage);
     if (s->d_tail_samples) (void)hipFree(s->d_tail_samples);
@@ -1149,6 +1114,8 @@ int ff_debug_check_ieee(FfState* s, unsigned long long* out_mismatches2)
     FF_HIP(hipStreamSynchronize(s->stream));
     return FF_OK;
 }
+
+const char* ff_debug_kernel_name(FfState* s) { return s && s->last_kernel_name ? s->last_kernel_name : ""; }
 
 int ff_stats(FfState* s, FfStats* out)
 {

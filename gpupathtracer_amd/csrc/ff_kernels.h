@@ -96,7 +96,9 @@ size_t pool_list_bytes(int pool_slots, int block_threads);
 size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads);
 
 // block_threads: 512 or 1024 for the BVH kernel; the brute-force kernel always runs 512.
-hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream);
+// *kernel_name (optional) receives the name of the instantiation launched, as rocprofv3 prints it.
+hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
+                        const char** kernel_name = nullptr);
 // Sums every pixel's sample blocks in order, scales by 1/spp and writes radiance / rgb8 (row-major, coalesced).
 hipError_t launch_combine(const KParams& p, hipStream_t stream);
 // sum = first_frame ? frame : sum + frame; mean = sum * inv_frames (and its 8-bit quantisation); `values` floats.
@@ -108,6 +110,10 @@ hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t
 hipError_t launch_ieee_check(unsigned long long* mismatches2, hipStream_t stream);
 hipError_t launch_deinterleave(const void* src, void* dst, int width, int height, int strip_rows, int num_parts, int elem_bytes,
                                hipStream_t stream);
+// Scatter of the gathered packed strips (ff_dist.cpp: per part [radiance rows][rgb8 rows], 16-byte padded sections) to
+// image order; rgb8 / radiance are the full-frame outputs (either may be null).
+hipError_t launch_unpack_strips(const void* src, unsigned char* rgb8, float* radiance, int width, int height, int strip_rows, int num_parts,
+                                hipStream_t stream);
 hipError_t prepare_kernels(); // one-time function attributes (dynamic LDS limit)
 
 } // namespace ff

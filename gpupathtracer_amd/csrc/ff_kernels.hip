@@ -1811,6 +1811,41 @@ __global__ void deinterleave_kernel(const unsigned char* __restrict__ src, unsig
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+// Multi-GPU gather, last step (ff_dist.cpp): `src` holds every part's packed strips, part after part, each part as
+// [rows x width float3 radiance][rows x width rgb8], both sections padded to 16 bytes; one pass scatters all rows of both
+// framebuffers to image order.  Row y belongs to strip y / strip_rows, which part (strip % num_parts) rendered as its
+// local strip strip / num_parts.
+__global__ void unpack_strips_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ rgb8, float* __restrict__ radiance, int width,
+                                     int height, int strip_rows, int num_parts)
+{
+    const int y = blockIdx.y;
+    if (y >= height) return;
+    const int nstrips = (height + strip_rows - 1) / strip_rows;
+    const int strip = y / strip_rows, part = strip % num_parts, local_strip = strip / num_parts;
+    auto part_rows = [&](int q) {
+        const int owned = (nstrips - q + num_parts - 1) / num_parts; // strips q, q + P, ...
+        size_t rows = (size_t)owned * (size_t)strip_rows;
+        if (owned > 0 && (nstrips - 1) % num_parts == q) rows -= (size_t)(nstrips * strip_rows - height); // the image's last strip may be short
+        return rows;
+    };
+    auto pad16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    size_t base = 0;
+    for (int q = 0; q < part; ++q) base += pad16(part_rows(q) * (size_t)width * 12) + pad16(part_rows(q) * (size_t)width * 3);
+    const size_t rows = part_rows(part);
+    const size_t local_row = (size_t)local_strip * (size_t)strip_rows + (size_t)(y - strip * strip_rows);
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (radiance) {
+        const float* s = reinterpret_cast<const float*>(src + base) + local_row * (size_t)width * 3;
+        float* d = radiance + (size_t)y * (size_t)width * 3;
+        for (size_t i = first; i < (size_t)width * 3; i += stride) d[i] = s[i];
+    }
+    if (rgb8) {
+        const unsigned char* s = src + base + pad16(rows * (size_t)width * 12) + local_row * (size_t)width * 3;
+        unsigned char* d = rgb8 + (size_t)y * (size_t)width * 3;
+        for (size_t i = first; i < (size_t)width * 3; i += stride) d[i] = s[i];
+    }
+}
+
 } // namespace
 
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms)
@@ -1860,15 +1895,18 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
-hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream)
+hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
+                        const char** kernel_name)
 {
     const dim3 grid(grid_blocks);
+    const char* name = "";
     if (trace_mode == FF_TRACE_BVH) {
         const dim3 block(block_threads);
         if (p.pool != nullptr) {
             const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, 1024, p.num_geoms) + pool_list_bytes(p.pool_slots, 1024);
             if (collect_stats) hipLaunchKernelGGL((trace_pool_kernel<true, 1024>), grid, dim3(1024), lds, stream, p);
             else hipLaunchKernelGGL((trace_pool_kernel<false, 1024>), grid, dim3(1024), lds, stream, p);
+            if (kernel_name) *kernel_name = collect_stats ? "trace_pool_kernel<true, 1024>" : "trace_pool_kernel<false, 1024>";
             return hipGetLastError();
         }
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
@@ -1876,11 +1914,11 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
         if (collect_stats) {                                                                                              \
-            if (spheres) hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p);              \
-            else hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p);                     \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false>"; } \
         } else {                                                                                                          \
-            if (spheres) hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p);             \
-            else hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p);                    \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false>"; } \
         }                                                                                                                 \
     } while (0)
         if (block_threads == 1024) FF_LAUNCH_BVH(1024);
@@ -1892,7 +1930,9 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
         const dim3 block(kBlockThreads);
         if (collect_stats) hipLaunchKernelGGL((trace_brute_kernel<true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((trace_brute_kernel<false>), grid, block, lds, stream, p);
+        name = collect_stats ? "trace_brute_kernel<true>" : "trace_brute_kernel<false>";
     }
+    if (kernel_name) *kernel_name = name;
     return hipGetLastError();
 }
 
@@ -1937,6 +1977,15 @@ hipError_t launch_deinterleave(const void* src, void* dst, int width, int height
     const dim3 grid(4, height), block(256);
     hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, stream, (const unsigned char*)src, (unsigned char*)dst, width, height,
                        strip_rows, num_parts, elem_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_strips(const void* src, unsigned char* rgb8, float* radiance, int width, int height, int strip_rows, int num_parts,
+                                hipStream_t stream)
+{
+    if (width <= 0 || height <= 0 || (!rgb8 && !radiance)) return hipSuccess;
+    const dim3 grid(std::max(1, std::min(8, (width * 3 + 255) / 256)), height), block(256);
+    hipLaunchKernelGGL(unpack_strips_kernel, grid, block, 0, stream, (const unsigned char*)src, rgb8, radiance, width, height, strip_rows, num_parts);
     return hipGetLastError();
 }
 

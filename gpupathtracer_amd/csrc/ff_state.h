@@ -1,0 +1,114 @@
+// ff_state.h — the tracer state behind the opaque FfState handle and the internal render steps shared by the
+// translation units of the library (ff_api.cpp: single-device entry points; ff_dist.cpp: multi-GPU entry points).
+#pragma once
+
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "ff_build.h"
+#include "ff_internal.h"
+#include "ff_kernels.h"
+
+struct FfDistContext; // ff_dist.cpp
+
+struct FfState {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    // scene (device)
+    ff::GeomRecord* d_geoms = nullptr;
+    ff::TriRecord* d_tris = nullptr;
+    ff::TriNormals* d_normals = nullptr; // vertex normals, parallel to d_tris
+    ff::BvhNode* d_nodes = nullptr;
+    int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
+    bool has_specular = false;
+    uint64_t num_tris = 0;
+    bool has_scene = false;
+    // scene bookkeeping for updates (ff_update_transforms / ff_update_mesh)
+    struct MeshSlot {
+        int node_first = 0, node_count = 0, node_capacity = 0, depth = 0;
+        bool parents_linked = false;
+    };
+    int builder = FF_BUILD_HOST_SAH;       // builder for the next upload (ff_set_builder)
+    int scene_builder = FF_BUILD_HOST_SAH; // builder that produced the scene on the device
+    std::vector<ff::GeomRecord> h_geoms;       // the uploaded records, processing order
+    std::vector<MeshSlot> slots;           // parallel to h_geoms (meshes only)
+    size_t node_capacity = 0;              // nodes allocated in d_nodes
+    int* d_parent = nullptr;               // node_capacity ints (refit)
+    FfTriangle* d_stage = nullptr;         // staging copy of a caller triangle array (device builder / refit)
+    size_t stage_bytes = 0;
+    ff::BuildScratch scratch;
+    FfBuildStats build_stats = {};
+    // work buffers (device)
+    float* d_blocksums = nullptr;
+    size_t blocksums_bytes = 0;
+    unsigned char* d_rgb8 = nullptr;
+    size_t rgb8_bytes = 0;
+    float* d_radiance = nullptr;
+    size_t radiance_bytes = 0;
+    // fine-grained tail (KParams::tail_samples)
+    float4* d_tail_samples = nullptr;
+    size_t tail_samples_bytes = 0;
+    int tail_group_spp = 32; // FF_TAIL_GROUP (0 = off); 32 measured best: 8 ranks +3.3 %, 1 rank +0.2 % (16: +3 % / -1.1 %, 8: +3 % / -5 %)
+    // progressive accumulation (ff_render_progressive)
+    float* d_accum = nullptr;
+    size_t accum_bytes = 0;
+    float* d_frame = nullptr;
+    size_t frame_bytes = 0;
+    float* d_mean = nullptr;
+    size_t mean_bytes = 0;
+    int accum_width = 0, accum_height = 0, accum_frames = 0;
+    unsigned* d_queue = nullptr;               // work-queue counter: lives right behind the counters (one memset clears both)
+    unsigned long long* d_counters = nullptr;  // 28 counters + 4 queue words
+    unsigned long long* h_counters = nullptr;  // pinned mirror for the per-frame read-back
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool collect_stats = false;
+    int block_threads = ff::kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
+    int scheduler = 0;      // 0 = time-sliced kernel, 1 = path-pool kernel (FF_SCHEDULER=pool)
+    int pool_slots = 192, pool_refill = 16, pool_low = 24;
+    unsigned* d_pool = nullptr;
+    size_t pool_bytes = 0;
+    int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
+                                                   // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
+    FfStats stats;
+    const char* last_kernel_name = nullptr; // trace kernel instantiation of the last frame (rocprofv3's spelling)
+    unsigned long long raw_counters[28] = {};
+    // GL interop
+    hipGraphicsResource* pbo_resource = nullptr;
+    int pbo_width = 0, pbo_height = 0;
+    // multi-GPU (ff_dist_init): communicator, rank and the packed strip / gather buffers
+    FfDistContext* dist = nullptr;
+    // a frame enqueued by render_enqueue and not yet finished by render_finish
+    int pending_launches = 0;
+    bool pending = false;
+    // fault injection for tests (FF_DEBUG_FAIL_ALLOC=k: the k-th scene allocation of every upload reports out-of-memory)
+    int debug_fail_alloc = -1, alloc_countdown = -1;
+};
+
+
+#define FF_HIP(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (call);                                                                               \
+        if (_e != hipSuccess) return fail(_e == hipErrorOutOfMemory ? FF_ERR_OOM : FF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+namespace ff {
+
+int ensure_bytes(void** ptr, size_t* cap, size_t need);
+
+// What every render entry point checks before it touches the device.
+int check_render_call(const FfState* s, const FfCamera* camera, const FfRenderParams* params, const char* who);
+
+// One frame (or this part's strips / one tile of it), in two steps so that several devices can work at once:
+// render_enqueue puts clears, trace launches, the combine pass and the counter read-back on the state's stream and
+// returns; render_finish waits for them and fills the state's FfStats.  rgb8_dev / radiance_dev are device pointers to
+// the LOCAL image (local_rows x win_w).  The window is [x0, x0 + win_w) x (y0 + the strip layout's rows); whole-width
+// strips pass x0 = y0 = 0, win_w = -1.
+int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm, int strip_rows, int part, int num_parts, int local_rows,
+                   unsigned char* rgb8_dev, float* radiance_dev, int x0 = 0, int y0 = 0, int win_w = -1);
+int render_finish(FfState* s);
+
+void dist_release(FfState* s); // ff_dist.cpp: frees s->dist (called by ff_destroy)
+
+} // namespace ff

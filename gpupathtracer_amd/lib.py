@@ -21,9 +21,13 @@ EXPORTS = [
     "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
-    "ff_set_collect_stats", "ff_stats", "ff_debug_counters", "ff_debug_check_ieee", "ff_load_obj", "ff_free_triangles",
+    "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_check_ieee", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
+    "ff_dist_unique_id", "ff_dist_init", "ff_dist_shutdown", "ff_dist_strip_rows", "ff_render_distributed",
+    "ff_multi_create", "ff_multi_destroy", "ff_multi_count", "ff_multi_state", "ff_multi_uses_rccl", "ff_multi_upload_scene",
+    "ff_multi_render", "ff_multi_render_to_pbo", "ff_multi_stats",
 ]
+DIST_ID_BYTES = 128
 
 _lib = None
 
@@ -84,6 +88,8 @@ def load():
     lib.ff_set_collect_stats.argtypes = [vp, i32]
     lib.ff_stats.argtypes = [vp, P(T.FfStats)]
     lib.ff_debug_counters.argtypes = [vp, P(C.c_ulonglong)]
+    lib.ff_debug_kernel_name.argtypes = [vp]
+    lib.ff_debug_kernel_name.restype = C.c_char_p
     lib.ff_debug_check_ieee.argtypes = [vp, P(C.c_ulonglong)]
     lib.ff_load_obj.argtypes = [C.c_char_p, P(P(T.FfTriangle)), P(i32)]
     lib.ff_free_triangles.argtypes = [P(T.FfTriangle)]
@@ -94,6 +100,21 @@ def load():
     lib.ff_scene_file_camera.argtypes = [vp, i32, i32, P(T.FfCamera)]
     lib.ff_scene_file_free.argtypes = [vp]
     lib.ff_scene_file_free.restype = None
+    lib.ff_dist_unique_id.argtypes = [vp, i32]
+    lib.ff_dist_init.argtypes = [vp, i32, i32, vp, i32]
+    lib.ff_dist_shutdown.argtypes = [vp]
+    lib.ff_dist_strip_rows.argtypes = [i32]
+    lib.ff_render_distributed.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, vp, i32, vp, i32]
+    lib.ff_multi_create.argtypes = [P(vp), P(i32), i32]
+    lib.ff_multi_destroy.argtypes = [vp]
+    lib.ff_multi_count.argtypes = [vp]
+    lib.ff_multi_state.argtypes = [vp, i32]
+    lib.ff_multi_state.restype = vp
+    lib.ff_multi_uses_rccl.argtypes = [vp]
+    lib.ff_multi_upload_scene.argtypes = [vp, P(T.FfGeometry), i32]
+    lib.ff_multi_render.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, vp, i32, vp, i32]
+    lib.ff_multi_render_to_pbo.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32]
+    lib.ff_multi_stats.argtypes = [vp, P(T.FfStats)]
     _lib = lib
     return lib
 
@@ -242,6 +263,10 @@ class Tracer:
         check(self._lib.ff_stats(self._state, C.byref(st)))
         return st
 
+    def kernel_name(self):
+        """Trace-kernel instantiation of the last frame, as rocprofv3 names it."""
+        return self._lib.ff_debug_kernel_name(self._state).decode()
+
     def check_ieee(self):
         """(reciprocal mismatches, square-root mismatches) of the kernels' lean IEEE sequences over all 2^32 floats."""
         buf = (C.c_ulonglong * 2)()
@@ -321,6 +346,93 @@ class Tracer:
         out = (T.FfIntersect * n)()
         check(self._lib.ff_intersect_rays(self._state, rbuf, n, out, trace_mode))
         return intersect_array(out, n)
+
+
+    # ---- multi-GPU, one process per GPU (ff_dist_*) ----
+
+    def dist_init(self, rank, world_size, unique_id):
+        """Join the job's RCCL communicator.  `unique_id`: the 128 bytes dist_unique_id() returned on rank 0."""
+        buf = (C.c_char * DIST_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(self._lib.ff_dist_init(self._state, rank, world_size, buf, DIST_ID_BYTES))
+
+    def dist_shutdown(self):
+        check(self._lib.ff_dist_shutdown(self._state))
+
+    def render_distributed(self, camera, params, strip_rows=0, rank=0, want_rgb8=True, want_radiance=True):
+        """One frame over all ranks; returns (rgb8, radiance) host arrays on rank 0, (None, None) elsewhere."""
+        h, w = params.height, params.width
+        root = rank == 0
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if want_rgb8 and root else None
+        rad = np.zeros((h, w, 3), dtype=np.float32) if want_radiance and root else None
+        check(self._lib.ff_render_distributed(self._state, C.byref(camera), C.byref(params), strip_rows,
+                                              rgb8.ctypes.data if rgb8 is not None else None, 0,
+                                              rad.ctypes.data if rad is not None else None, 0))
+        return rgb8, rad
+
+    def render_distributed_device(self, camera, params, strip_rows=0, rgb8_ptr=None, radiance_ptr=None):
+        """The same into caller-owned device buffers on rank 0 (raw pointers; ignored on other ranks)."""
+        check(self._lib.ff_render_distributed(self._state, C.byref(camera), C.byref(params), strip_rows,
+                                              C.c_void_p(rgb8_ptr) if rgb8_ptr else None, 1,
+                                              C.c_void_p(radiance_ptr) if radiance_ptr else None, 1))
+
+
+def dist_unique_id():
+    """128-byte RCCL id for Tracer.dist_init (call on rank 0, hand to the other ranks)."""
+    buf = (C.c_char * DIST_ID_BYTES)()
+    check(load().ff_dist_unique_id(buf, DIST_ID_BYTES))
+    return bytes(buf)
+
+
+def dist_strip_rows(world_size):
+    return load().ff_dist_strip_rows(world_size)
+
+
+class MultiTracer:
+    """Several GPUs driven by ONE process (ff_multi_*): what a single-process viewer calls.  device_ids[0] gathers."""
+
+    def __init__(self, device_ids):
+        self._lib = load()
+        self._handle = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        check(self._lib.ff_multi_create(C.byref(self._handle), ids, len(device_ids)))
+
+    def close(self):
+        if self._handle:
+            self._lib.ff_multi_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self):
+        return self._lib.ff_multi_count(self._handle)
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.ff_multi_uses_rccl(self._handle))
+
+    def upload_scene(self, scene):
+        check(self._lib.ff_multi_upload_scene(self._handle, scene.geometries, len(scene)))
+
+    def render(self, camera, params, strip_rows=0, want_rgb8=True, want_radiance=True):
+        h, w = params.height, params.width
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if want_rgb8 else None
+        rad = np.zeros((h, w, 3), dtype=np.float32) if want_radiance else None
+        check(self._lib.ff_multi_render(self._handle, C.byref(camera), C.byref(params), strip_rows,
+                                        rgb8.ctypes.data if want_rgb8 else None, 0, rad.ctypes.data if want_radiance else None, 0))
+        return rgb8, rad
+
+    def render_device(self, camera, params, strip_rows=0, rgb8_ptr=None, radiance_ptr=None):
+        check(self._lib.ff_multi_render(self._handle, C.byref(camera), C.byref(params), strip_rows,
+                                        C.c_void_p(rgb8_ptr) if rgb8_ptr else None, 1, C.c_void_p(radiance_ptr) if radiance_ptr else None, 1))
+
+    def stats(self):
+        st = T.FfStats()
+        check(self._lib.ff_multi_stats(self._handle, C.byref(st)))
+        return st
 
 
 INTERSECT_DTYPE = np.dtype([("point", np.float32, 3), ("normal", np.float32, 3), ("t", np.float32), ("hit", np.uint8),

@@ -152,7 +152,7 @@ SHADE_NORMAL_DEBUG, SHADE_DIFFUSE_PATH, SHADE_DIFFUSE_PATH_SMOOTH = 0, 1, 2
 GRID_FULL, GRID_REFERENCE_FLOOR = 0, 1
 
 # status codes (ff_api.h)
-FF_OK, FF_ERR_INVALID_ARG, FF_ERR_NO_DEVICE, FF_ERR_HIP, FF_ERR_NO_SCENE, FF_ERR_UNSUPPORTED, FF_ERR_GL_UNAVAILABLE, FF_ERR_IO, FF_ERR_OOM = range(9)
+FF_OK, FF_ERR_INVALID_ARG, FF_ERR_NO_DEVICE, FF_ERR_HIP, FF_ERR_NO_SCENE, FF_ERR_UNSUPPORTED, FF_ERR_GL_UNAVAILABLE, FF_ERR_IO, FF_ERR_OOM, FF_ERR_COMM = range(10)
 
 TRIANGLE_DTYPE = np.dtype((np.float32, (24,)))
 

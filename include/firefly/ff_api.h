@@ -41,7 +41,8 @@ typedef enum FfStatus {
     FF_ERR_UNSUPPORTED    = 5,  /* e.g. a non-affine model matrix, an unknown geometry type (kernel.cu:170-173) */
     FF_ERR_GL_UNAVAILABLE = 6,  /* HIP-GL interop not usable (headless box) */
     FF_ERR_IO             = 7,  /* file could not be read / parsed */
-    FF_ERR_OOM            = 8
+    FF_ERR_OOM            = 8,
+    FF_ERR_COMM           = 9   /* RCCL unavailable or a collective call failed (multi-GPU entry points) */
 } FfStatus;
 
 typedef struct FfState FfState; /* opaque; replaces PathTracerState (kernel.h:12-20) */
@@ -158,6 +159,48 @@ FF_API int ff_strips_local_rows(int height, int strip_rows, int part, int num_pa
 FF_API int ff_deinterleave_strips(FfState* state, const void* src_dev, void* dst_dev, int width, int height,
                                   int strip_rows, int num_parts, int elem_bytes);
 
+/* ---- multi-GPU frames (no counterpart in the reference: its only trace of more than one GPU is the dead
+ *      `const bool multi_gpu` of utilities.h:484-487; BASELINE north star: image tiles over the GPUs of a node, RCCL
+ *      gather of the framebuffer over xGMI) ---------------------------------------------------------------------- */
+
+/* Shape 1 — one process per GPU.  Rank 0 obtains an id (128 bytes) and hands it to the other ranks by any means it has
+ * (a file, a socket, MPI, torch.distributed); every rank then joins with its own state.  One RCCL communicator per state. */
+#define FF_DIST_ID_BYTES 128
+FF_API int ff_dist_unique_id(void* out_id, int bytes);
+FF_API int ff_dist_init(FfState* state, int rank, int world_size, const void* id, int bytes);
+FF_API int ff_dist_shutdown(FfState* state);
+
+/* Strip height the distributed renderers use when given strip_rows <= 0: 16 rows for up to 2 GPUs, 8 up to 4, else 4. */
+FF_API int ff_dist_strip_rows(int world_size);
+
+/* One frame over all ranks; every rank calls it with the same camera and params.  Each rank renders the strips
+ * s % world == rank (ff_render_strips' partition) into one packed buffer and sends it to rank 0 in a single message;
+ * rank 0 receives every peer's message into its gather buffer (one grouped RCCL call) and scatters all strips to image
+ * order.  On rank 0, rgb8 / radiance receive the full frame, bit-identical to ff_render's (device or host pointers, as
+ * there); on other ranks they are ignored.  Synchronous on return on every rank; ff_stats reports this rank's share. */
+FF_API int ff_render_distributed(FfState* state, const FfCamera* camera, const FfRenderParams* params, int strip_rows,
+                                 void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device);
+
+/* Shape 2 — one process, several GPUs: what a single-process viewer (the reference's main(), kernel.cu:223-368) calls.
+ * ff_multi_create makes one state per entry of device_ids, each with its own stream; device_ids[0] is the gathering device
+ * (the one whose GL context owns the pixel buffer).  Transport: RCCL (ncclCommInitAll + grouped send/recv); peer copies
+ * (hipMemcpyPeerAsync) when a device id repeats — RCCL refuses that, and it is how a one-GPU box rehearses the path — or
+ * when FF_MULTI_TRANSPORT=peer. */
+typedef struct FfMulti FfMulti;
+FF_API int ff_multi_create(FfMulti** out_multi, const int* device_ids, int n);
+FF_API int ff_multi_destroy(FfMulti* multi);
+FF_API int ff_multi_count(const FfMulti* multi);
+FF_API FfState* ff_multi_state(FfMulti* multi, int index);       /* per-device calls: ff_register_gl_pbo on index 0, ff_set_builder, ... */
+FF_API int ff_multi_uses_rccl(const FfMulti* multi);
+FF_API int ff_multi_upload_scene(FfMulti* multi, const FfGeometry* host_geometries, int n); /* replicated on every device */
+/* The frame: all devices render their strips at once, device 0 gathers.  Outputs as in ff_render, on / from device 0. */
+FF_API int ff_multi_render(FfMulti* multi, const FfCamera* camera, const FfRenderParams* params, int strip_rows,
+                           void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device);
+/* kernel.cu:335-344 with all GPUs behind it: the pixel buffer registered on ff_multi_state(multi, 0). */
+FF_API int ff_multi_render_to_pbo(FfMulti* multi, const FfCamera* camera, const FfRenderParams* params, int strip_rows);
+/* Sums over the devices of the last frame (kernel_ms: the slowest device). */
+FF_API int ff_multi_stats(FfMulti* multi, FfStats* out);
+
 /* Batch closest-hit query = intersectRays (kernel.cu:127-176) for `n` arbitrary world-space rays.
  * rays/out are host arrays. trace_mode is an FfTraceMode. */
 FF_API int ff_intersect_rays(FfState* state, const FfRay* rays, int n, FfIntersect* out, int trace_mode);
@@ -193,6 +236,9 @@ FF_API int ff_save_ppm(const char* path, const unsigned char* rgb8, int width, i
 /* Turn per-launch node/triangle visit counters on (1) or off (0, default).  Ray counting is always on. */
 FF_API int ff_set_collect_stats(FfState* state, int on);
 FF_API int ff_stats(FfState* state, FfStats* out);
+
+/* Name of the trace-kernel instantiation the last frame launched, spelled as rocprofv3 prints it ("" before the first frame). */
+FF_API const char* ff_debug_kernel_name(FfState* state);
 
 /* Raw device counters of the last instrumented render (ff_set_collect_stats(1)), 28 values: [0] rays [1] inner-node
  * visits [2] triangle tests [3] plane tests (all summed over lanes) [8] inner-step rounds [9] leaf rounds [10] triangle

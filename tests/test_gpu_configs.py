@@ -123,16 +123,17 @@ def test_c4_path_mode_bvh_equals_brute_force(c4_scene, builder):
 
 
 def test_c4_path_mode_matches_the_oracle_crop(tracer, c4_scene):
-    """The same config against the CPU oracle (brute force over 983 040 triangles) on a 12x8 crop on the sphere."""
+    """The same config against the CPU oracle (brute force over 983 040 triangles) on a 14x8 crop across the sphere's
+    silhouette (on the sphere itself most paths leave through the open front after two segments and stay black)."""
     cam = _inside(1920, 1080)
-    x0, y0, w, h = 1000, 500, 12, 8
+    x0, y0, w, h = 1226, 324, 14, 8
     tracer.upload_scene(c4_scene)
-    params = lib.render_params(1920, 1080, 8, 2, seed=11)
+    params = lib.render_params(1920, 1080, 8, 6, seed=11)
     got = tracer.render_tile(cam, params, x0, y0, w, h)
     exp = oracle_render(c4_scene, cam, params, window=(x0, y0, w, h), threads=16)
     assert _same(got, exp) and exp[1].max() > 0
     # smooth shading reads the vertex normals of the subdivided mesh through the same tree
-    smooth = lib.render_params(1920, 1080, 4, 2, seed=11, shade_mode=T.SHADE_DIFFUSE_PATH_SMOOTH)
+    smooth = lib.render_params(1920, 1080, 8, 6, seed=11, shade_mode=T.SHADE_DIFFUSE_PATH_SMOOTH)
     got = tracer.render_tile(cam, smooth, x0, y0, w, h)
     exp = oracle_render(c4_scene, cam, smooth, window=(x0, y0, w, h), threads=16)
-    assert _same(got, exp)
+    assert _same(got, exp) and exp[1].max() > 0
