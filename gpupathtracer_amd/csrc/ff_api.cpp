@@ -3,6 +3,7 @@
 // kernel.cu:335-344 (per-frame map -> clear -> kernel -> unmap).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -24,7 +25,15 @@ void free_scene(FfState* s)
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_normals) (void)hipFree(s->d_normals);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_nodes4) (void)hipFree(s->d_nodes4);
+    if (s->d_tlas) (void)hipFree(s->d_tlas);
+    s->d_tlas = nullptr;
+    s->tlas_bytes = 0;
+    s->tlas_depth = 0;
     if (s->d_parent) (void)hipFree(s->d_parent);
+    s->d_nodes4 = nullptr;
+    s->num_nodes4 = s->max_depth4 = 0;
+    s->scene_block_threads = s->lds_cap = 0;
     s->d_geoms = nullptr;
     s->d_tris = nullptr;
     s->d_normals = nullptr;
@@ -93,14 +102,15 @@ int check_render_call(const FfState* s, const FfCamera* camera, const FfRenderPa
     const int st = check_params(params);
     if (st != FF_OK) return st;
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "%s: no scene uploaded", who);
-    if (params->trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
-        return fail(FF_ERR_UNSUPPORTED, "%s: BVH mode supports at most %d geometries (scene has %d)", who, kMaxGeometriesBvh, s->num_geoms);
     return FF_OK;
 }
 
 } // namespace ff
 
 namespace {
+
+// Geometry records the BVH kernels keep in LDS: all of them up to kChunkGeometries, none beyond (read from global memory).
+int lds_records(const FfState* s) { return s->num_geoms > kChunkGeometries ? 0 : s->num_geoms; }
 
 // Workgroup size of the BVH kernel for the uploaded scene: the preferred size if the lane-strided traversal stacks
 // (4 bytes x workgroup size per tree level) and the geometry records fit the 160 KiB of LDS, else the largest smaller
@@ -110,9 +120,93 @@ int bvh_block_threads(const FfState* s, int preferred)
     const int sizes[3] = { 1024, 768, 512 };
     for (int b : sizes) {
         if (b > preferred) continue;
-        if (bvh_lds_bytes(0, s->max_depth + 1, b, s->num_geoms) <= (size_t)kLdsBudgetBytes) return b;
+        if (bvh_lds_bytes(0, s->stack_entries, b, lds_records(s)) <= (size_t)kLdsBudgetBytes) return b;
     }
     return 0;
+}
+
+// After every change of the trees (upload, rebuild) or of the records (transform update): choose the BVH kernel's
+// workgroup size for the scene, divide the LDS node slots among the meshes (each mesh caches the top of its 4-wide tree:
+// its first lds_nodes nodes) and write that into the geometry records, then copy the records to the device.
+int finalize_layout(FfState* s)
+{
+    int nodes4 = 0, depth4 = 0;
+    for (size_t i = 0; i < s->slots.size(); ++i) {
+        if (s->h_geoms[i].type != FF_GEOM_TRIANGLEMESH || s->slots[i].node4_count == 0) continue;
+        nodes4 += s->slots[i].node4_count;
+        depth4 = std::max(depth4, s->slots[i].depth4);
+    }
+    s->num_nodes4 = nodes4;
+    s->max_depth4 = depth4;
+    // Scenes of more than kChunkGeometries geometries: the tree over the geometries' world boxes (rebuilt here because
+    // transforms and refits move those boxes; a few hundred records take microseconds).
+    s->tlas_depth = 0;
+    if (s->num_geoms > kChunkGeometries) {
+        std::vector<BvhNode> top;
+        s->tlas_depth = build_geometry_tree(s->h_geoms, top);
+        int st = ensure_bytes((void**)&s->d_tlas, &s->tlas_bytes, top.size() * sizeof(BvhNode));
+        if (st != FF_OK) return st;
+        FF_HIP(hipMemcpyAsync(s->d_tlas, top.data(), top.size() * sizeof(BvhNode), hipMemcpyHostToDevice, s->stream));
+        FF_HIP(hipStreamSynchronize(s->stream)); // (`top` goes out of scope)
+    }
+    // one entry per visited node above the cursor (inner_step) plus a spare; below them, in big scenes, the pending entries
+    // of the walk through the geometry tree: at most one sibling per level plus the two children just pushed
+    s->stack_entries = depth4 + 1 + (s->tlas_depth > 0 ? s->tlas_depth + 2 : 0);
+    if (!s->setup_threshold_forced) {
+        // Traversal time slice, in inner-node rounds (trace_bvh_kernel): long enough for most queries of the scene's biggest
+        // tree to finish inside one slice.  Measured best on one MI355X: 6-8 for C2 (1 000 nodes, 4.4 visits per ray), 14-20
+        // for the 983 040-triangle sphere (180 000 nodes, 12.8 visits); both sit on 2 log4(nodes) - 4.
+        int biggest = 1;
+        for (size_t i = 0; i < s->slots.size(); ++i) biggest = std::max(biggest, s->slots[i].node4_count);
+        s->setup_threshold = std::max(4, std::min(24, (int)std::lround(2.0 * std::log((double)biggest) / std::log(4.0) - 3.9)));
+    }
+    s->scene_block_threads = bvh_block_threads(s, s->block_threads);
+    // (a tree too deep even for 512 threads still uploads: brute-force rendering works, BVH rendering reports it)
+    const int block = s->scene_block_threads > 0 ? s->scene_block_threads : kBlockThreads;
+    const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_entries, block, lds_records(s))) : 0;
+    s->lds_cap = std::min(cap, nodes4);
+    int next = 0;
+    for (size_t i = 0; i < s->h_geoms.size(); ++i) {
+        GeomRecord& r = s->h_geoms[i];
+        r.node4_first = 0;
+        r.lds_nodes = 0;
+        r.wmin[3] = 0.0f;
+        if (r.type != FF_GEOM_TRIANGLEMESH || s->slots[i].node4_count == 0) continue;
+        const int count = s->slots[i].node4_count;
+        // everything if it fits, else a share proportional to the tree's size (the top levels of every tree)
+        const int share = nodes4 <= cap ? count : (int)((int64_t)cap * count / nodes4);
+        r.node4_first = s->slots[i].node_first;
+        r.lds_nodes = std::min(count, share);
+        std::memcpy(&r.wmin[3], &next, sizeof(int));
+        next += r.lds_nodes;
+    }
+    FF_HIP(hipMemcpyAsync(s->d_geoms, s->h_geoms.data(), s->h_geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice, s->stream));
+    FF_HIP(hipStreamSynchronize(s->stream));
+    return FF_OK;
+}
+
+// Derive mesh slot `gi`'s 4-wide tree from its binary tree (after a build: with_info, one stream synchronisation; after a
+// refit: boxes only, asynchronous).
+int collapse_slot(FfState* s, size_t gi, bool with_info)
+{
+    FfState::MeshSlot& slot = s->slots[gi];
+    if (slot.node_count <= 0) return FF_OK;
+    int st = FF_OK;
+    if (!slot.parents_linked) {
+        st = gpu_link_parents(s->stream, s->d_nodes, slot.node_first, slot.node_count, s->d_parent + slot.node_first);
+        if (st != FF_OK) return st;
+        slot.parents_linked = true;
+    }
+    Collapse4Info info;
+    st = gpu_collapse_mesh(s->stream, s->scratch, s->d_nodes, slot.node_first, slot.node_count, s->d_parent + slot.node_first, s->d_nodes4, slot.node_first,
+                           with_info ? &info : nullptr);
+    if (st != FF_OK) return st;
+    if (with_info) {
+        if (info.node_count >= (1 << 22)) return fail(FF_ERR_UNSUPPORTED, "a mesh's tree has %d 4-wide nodes; the traversal stack encodes at most %d", info.node_count, (1 << 22) - 1);
+        slot.node4_count = info.node_count;
+        slot.depth4 = info.depth;
+    }
+    return FF_OK;
 }
 
 } // namespace
@@ -204,21 +298,17 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.geoms = s->d_geoms;
     k.tris = s->d_tris;
     k.trinormals = prm->shade_mode == FF_SHADE_DIFFUSE_PATH_SMOOTH ? reinterpret_cast<const float4*>(s->d_normals) : nullptr;
-    k.nodes = s->d_nodes;
+    k.nodes4 = s->d_nodes4;
     int block_threads = kBlockThreads;
     if (prm->trace_mode == FF_TRACE_BVH) {
-        block_threads = bvh_block_threads(s, s->block_threads);
+        block_threads = s->scene_block_threads;
         if (block_threads == 0)
-            return fail(FF_ERR_UNSUPPORTED, "BVH of depth %d does not fit the LDS traversal stack (512 threads x %d levels + %d geometry records > 160 KiB); "
-                        "upload with FF_BUILD_HOST_SAH (depth <= 30) or render with FF_TRACE_BRUTE_FORCE", s->max_depth, s->max_depth + 1, s->num_geoms);
+            return fail(FF_ERR_UNSUPPORTED, "4-wide BVH of depth %d does not fit the LDS traversal stack (512 threads x %d levels + %d geometry records > 160 KiB); "
+                        "upload with FF_BUILD_HOST_SAH or render with FF_TRACE_BRUTE_FORCE", s->max_depth4, s->max_depth4 + 1, s->num_geoms);
     }
-    k.stack_depth = s->max_depth + 1; // at most one pending sibling per level above the cursor, plus one spare slot
-    // (the experimental pool scheduler handles single-chunk scenes only)
-    const bool use_pool = prm->trace_mode == FF_TRACE_BVH && s->scheduler == 1 && s->num_geoms <= 32 && block_threads == 1024;
-    int fit = max_lds_nodes(k.stack_depth, use_pool ? 1024 : block_threads, s->num_geoms);
-    if (use_pool) fit -= (int)((pool_list_bytes(s->pool_slots, 1024) + sizeof(BvhNode) - 1) / sizeof(BvhNode));
-    k.lds_nodes = s->num_nodes < fit ? s->num_nodes : fit;
-    if (k.lds_nodes < 0) k.lds_nodes = 0;
+    k.stack_depth = s->stack_entries;
+    k.lds_nodes = s->lds_cap;
+    k.tlas = s->tlas_depth > 0 ? s->d_tlas : nullptr;
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
@@ -230,16 +320,6 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
 
-    if (use_pool) {
-        k.items_per_fetch = 1; // (a pool slot's Path does not keep a run between fetches)
-        const size_t need = pool_workspace_bytes(s->pool_slots, grid, 1024);
-        int pst = ensure_bytes((void**)&s->d_pool, &s->pool_bytes, need);
-        if (pst != FF_OK) return pst;
-        k.pool = s->d_pool;
-        k.pool_slots = s->pool_slots;
-        k.pool_refill = s->pool_refill;
-        k.pool_low = s->pool_low;
-    }
     hipStream_t st = s->stream;
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced pixels read 0.  With the full grid the combine pass writes every pixel
     // of the window (a missed pixel gets its zero sum), so the clears are only needed for the reference's floor grid.
@@ -253,9 +333,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     // as 16-sample items with per-sample storage (see KParams::tail_samples).
     k.tail_block = -1;
     const int last_launch_blocks = num_blocks - (launches - 1) * blocks_per_launch;
-    const bool tail_mode = !debug && prm->trace_mode == FF_TRACE_BVH && !use_pool && s->tail_group_spp > 0 && last_launch_blocks >= 4 &&
-                           s->tail_group_spp < block_spp &&
-                           (uint64_t)k.pix_items * (uint64_t)block_spp * sizeof(float4) <= (4ull << 30); // (also keeps slot indices in 31 bits)
+    // It pays where a launch is short (a rank of a multi-GPU frame: +3.3 % at eight ranks) and costs a per-sample buffer
+    // (2.1 GB written and read back at 1080p) that a one-GPU frame does not earn back (+0.2 %): on by default only for
+    // multi-part frames; FF_TAIL_GROUP forces it.  Frames whose buffer would pass 4 GiB render without it (FfStats::flags).
+    const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && last_launch_blocks >= 4 &&
+                             s->tail_group_spp < block_spp && (num_parts > 1 || s->tail_forced);
+    const bool tail_mode = tail_wanted && (uint64_t)k.pix_items * (uint64_t)block_spp * sizeof(float4) <= (4ull << 30); // (also keeps slot indices in 31 bits)
+    s->pending_flags = (tail_mode ? FF_STATS_TAIL_ITEMS : 0u) | (tail_wanted && !tail_mode ? FF_STATS_TAIL_SKIPPED_TOO_LARGE : 0u);
     if (tail_mode) {
         int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, (size_t)k.pix_items * (size_t)block_spp * sizeof(float4));
         if (tst != FF_OK) return tst;
@@ -274,11 +358,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
         k.block_end = std::min(num_blocks, (l + 1) * blocks_per_launch);
-        k.total_items = k.pix_items * (unsigned)(k.block_end - k.block_begin);
+        k.whole_blocks = (unsigned)(k.block_end - k.block_begin);
+        k.total_items = k.pix_items * k.whole_blocks;
         if (tail_mode && l == launches - 1) {
             const unsigned groups = (unsigned)k.tail_groups;
             k.tail_block = num_blocks - 1;
-            k.tail_first_item = k.pix_items * (unsigned)(k.block_end - 1 - k.block_begin);
+            k.whole_blocks = (unsigned)(k.block_end - 1 - k.block_begin);
+            k.tail_first_item = k.pix_items * k.whole_blocks;
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
         if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
@@ -308,7 +394,8 @@ int render_finish(FfState* s)
     s->stats.planes_tested = c[3];
     s->stats.kernel_ms = ms;
     s->stats.kernel_launches = (uint32_t)s->pending_launches;
-    s->stats.scene_bytes_nodes = (uint64_t)s->num_nodes * sizeof(BvhNode);
+    s->stats.flags = s->pending_flags;
+    s->stats.scene_bytes_nodes = (uint64_t)s->num_nodes4 * sizeof(Bvh4Node);
     s->stats.scene_bytes_tris = s->num_tris * sizeof(TriRecord);
     return FF_OK;
 }
@@ -350,12 +437,14 @@ int ff_create(FfState** out_state, int device_id)
         if (v == 512 || v == 768 || v == 1024) s->block_threads = v;
     }
     if (const char* e = std::getenv("FF_DEBUG_FAIL_ALLOC")) s->debug_fail_alloc = std::atoi(e);
-    if (const char* e = std::getenv("FF_TAIL_GROUP")) s->tail_group_spp = std::max(0, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) s->setup_threshold = std::max(0, std::min(1 << 14, std::atoi(e)));
-    if (const char* e = std::getenv("FF_SCHEDULER")) s->scheduler = std::strcmp(e, "pool") == 0 ? 1 : 0;
-    if (const char* e = std::getenv("FF_POOL_SLOTS")) s->pool_slots = std::max(64, std::min(1024, std::atoi(e)));
-    if (const char* e = std::getenv("FF_POOL_REFILL")) s->pool_refill = std::max(1, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("FF_POOL_LOW")) s->pool_low = std::max(1, std::min(65, std::atoi(e)));
+    if (const char* e = std::getenv("FF_TAIL_GROUP")) {
+        s->tail_group_spp = std::max(0, std::min(64, std::atoi(e)));
+        s->tail_forced = true;
+    }
+    if (const char* e = std::getenv("FF_SETUP_THRESHOLD")) {
+        s->setup_threshold = std::max(0, std::min(1 << 14, std::atoi(e)));
+        s->setup_threshold_forced = true;
+    }
     if (const char* e = std::getenv("FF_LEAF_THRESHOLD")) s->leaf_threshold = std::max(1, std::min(64, std::atoi(e)));
     hipError_t pe = prepare_kernels();
     if (pe != hipSuccess) {
@@ -387,7 +476,6 @@ int ff_destroy(FfState* s)
     if (s->d_mean) (void)hipFree(s->d_mean);
     free_build_scratch(s->scratch);
     if (s->d_blocksums) (void)hipFree(s->d_blocksums);
-    if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_rgb8) (void)hipFree(s->d_rgb8);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -493,6 +581,8 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     FF_HIP(scene_alloc(s, (void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
     FF_HIP(scene_alloc(s, (void**)&s->d_normals, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriNormals)));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (node_cap ? node_cap : 1) * sizeof(Bvh4Node)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_parent, (node_cap ? node_cap : 1) * sizeof(int)));
     s->node_capacity = node_cap;
     s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
     int node_base = 0;
@@ -519,10 +609,15 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
             slot.node_count = info.node_count;
             slot.depth = info.depth;
         }
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            st = collapse_slot(s, gi, /*with_info=*/true);
+            if (st != FF_OK) return st;
+            bs.build_ms += ms_since(t0);
+        }
         r.bvh_root = node_base;
         node_base += slot.node_capacity;
     }
-    FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
     s->h_geoms = cs.geoms;
     s->num_geoms = (int)cs.geoms.size();
     s->num_planes = s->num_quads = 0;
@@ -535,6 +630,8 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     s->num_tris = cs.total_tris;
     s->scene_builder = s->builder;
     refresh_scene_extent(s);
+    st = finalize_layout(s);
+    if (st != FF_OK) return st;
     s->has_scene = true;
     return FF_OK;
 }
@@ -590,7 +687,6 @@ int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, cons
     const auto t_copy = std::chrono::steady_clock::now();
     // One allocation + one copy per array (the reference issues a cudaMallocManaged + two cudaMemcpy per geometry, kernel.cu:277-298).
     FF_HIP(scene_alloc(s, (void**)&s->d_geoms, cs.geoms.size() * sizeof(GeomRecord)));
-    FF_HIP(hipMemcpy(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice));
     // Keep the triangle / node arrays non-null so the kernels can form addresses even for plane-only scenes.
     const size_t tri_bytes = (cs.tris.size() ? cs.tris.size() : 1) * sizeof(TriRecord);
     const size_t node_bytes = (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(BvhNode);
@@ -599,6 +695,8 @@ int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, cons
     static_assert(sizeof(TriNormals) == sizeof(TriRecord), "parallel arrays of equal stride");
     if (!cs.normals.empty()) FF_HIP(hipMemcpy(s->d_normals, cs.normals.data(), cs.normals.size() * sizeof(TriNormals), hipMemcpyHostToDevice));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, node_bytes));
+    FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(Bvh4Node)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_parent, (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(int)));
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     s->build_stats.copy_ms = ms_since(t_copy);
@@ -635,6 +733,15 @@ int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, cons
     s->max_depth = cs.max_depth;
     s->build_stats.bvh_nodes = s->num_nodes;
     s->build_stats.bvh_max_depth = s->max_depth;
+    // the 4-wide trees the kernels traverse, derived on the device from the binary ones just copied
+    const auto t_collapse = std::chrono::steady_clock::now();
+    for (size_t gi = 0; gi < s->slots.size(); ++gi) {
+        st = collapse_slot(s, gi, /*with_info=*/true);
+        if (st != FF_OK) return st;
+    }
+    s->build_stats.build_ms += ms_since(t_collapse);
+    st = finalize_layout(s);
+    if (st != FF_OK) return st;
     s->has_scene = true;
     return FF_OK;
 }
@@ -661,9 +768,9 @@ int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
         a.bvh_root = b.bvh_root;
     }
     FF_HIP(hipSetDevice(s->device));
-    FF_HIP(hipMemcpyAsync(s->d_geoms, cs.geoms.data(), cs.geoms.size() * sizeof(GeomRecord), hipMemcpyHostToDevice, s->stream));
-    FF_HIP(hipStreamSynchronize(s->stream));
     s->h_geoms = cs.geoms;
+    st = finalize_layout(s); // (fills the records' tree fields again and copies them to the device)
+    if (st != FF_OK) return st;
     s->has_specular = false; // materials may have changed
     for (const GeomRecord& g : cs.geoms) s->has_specular = s->has_specular || g.bxdf_type == FF_BXDF_MIRROR || g.bxdf_type == FF_BXDF_GLASS;
     s->build_stats.last_operation = 3;
@@ -714,9 +821,13 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
             return st;
         }
         slot.parents_linked = false;
+        st = collapse_slot(s, (size_t)gi, /*with_info=*/true);
+        if (st != FF_OK) {
+            s->has_scene = false;
+            return st;
+        }
         bs.last_operation = 2;
     } else {
-        if (!s->d_parent) FF_HIP(hipMalloc((void**)&s->d_parent, (s->node_capacity ? s->node_capacity : 1) * sizeof(int)));
         if (!slot.parents_linked) {
             st = gpu_link_parents(s->stream, s->d_nodes, slot.node_first, slot.node_count, s->d_parent + slot.node_first);
             if (st != FF_OK) return st;
@@ -724,6 +835,8 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
         }
         st = gpu_refit_mesh(s->stream, s->scratch, s->d_stage, count, rec.tri_first, slot.node_first, slot.node_count, s->d_parent + slot.node_first, s->d_tris,
                             s->d_normals, s->d_nodes);
+        if (st != FF_OK) return st;
+        st = collapse_slot(s, (size_t)gi, /*with_info=*/false); // same topology: the boxes of the 4-wide nodes follow
         if (st != FF_OK) return st;
         bs.last_operation = 1;
     }
@@ -737,11 +850,11 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
         }
     }
     set_world_box(rec, omn, omx);
-    FF_HIP(hipMemcpyAsync(s->d_geoms + gi, &rec, sizeof(GeomRecord), hipMemcpyHostToDevice, s->stream));
-    FF_HIP(hipStreamSynchronize(s->stream));
-    bs.build_ms = ms_since(t_build);
     refresh_scene_extent(s);
     if (s->scene_builder == FF_BUILD_HOST_SAH) s->num_nodes = (int)s->node_capacity;
+    st = finalize_layout(s); // (a rebuilt tree may differ in size and depth: LDS shares and workgroup size follow; copies the records)
+    if (st != FF_OK) return st;
+    bs.build_ms = ms_since(t_build);
     bs.total_ms = ms_since(t_call);
     return FF_OK;
 }
@@ -776,6 +889,34 @@ int ff_debug_download_bvh(FfState* s, void* nodes, int max_nodes, int* out_nodes
             row[2] = g.tri_first;
             row[3] = g.tri_count;
             row[4] = mesh ? s->slots[i].depth : 0;
+        }
+    }
+    return FF_OK;
+}
+
+int ff_debug_download_bvh4(FfState* s, void* nodes4, int max_nodes, int* out_capacity, int* mesh_table, int max_geometries)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_debug_download_bvh4: state is null");
+    if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_debug_download_bvh4: no scene uploaded");
+    if (out_capacity) *out_capacity = (int)s->node_capacity;
+    FF_HIP(hipSetDevice(s->device));
+    if (nodes4 && max_nodes > 0)
+        FF_HIP(hipMemcpy(nodes4, s->d_nodes4, (size_t)std::min<size_t>((size_t)max_nodes, s->node_capacity) * sizeof(Bvh4Node), hipMemcpyDeviceToHost));
+    if (mesh_table) {
+        for (size_t i = 0; i < s->h_geoms.size(); ++i) {
+            const GeomRecord& g = s->h_geoms[i];
+            if (g.orig_index < 0 || g.orig_index >= max_geometries) continue;
+            int* row = mesh_table + 6 * g.orig_index;
+            const bool mesh = g.type == FF_GEOM_TRIANGLEMESH && g.bvh_root >= 0;
+            int lds_first = 0;
+            std::memcpy(&lds_first, &g.wmin[3], sizeof(int));
+            row[0] = mesh ? g.node4_first : -1;
+            row[1] = mesh ? s->slots[i].node4_count : 0;
+            row[2] = mesh ? s->slots[i].depth4 : 0;
+            row[3] = mesh ? lds_first : 0;
+            row[4] = mesh ? g.lds_nodes : 0;
+            row[5] = s->lds_cap;
         }
     }
     return FF_OK;
@@ -894,11 +1035,9 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     if (n < 0) return fail(FF_ERR_INVALID_ARG, "ff_intersect_rays: negative count");
     if (trace_mode != FF_TRACE_BRUTE_FORCE && trace_mode != FF_TRACE_BVH) return fail(FF_ERR_INVALID_ARG, "unknown trace_mode %d", trace_mode);
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_intersect_rays: no scene uploaded");
-    if (trace_mode == FF_TRACE_BVH && s->num_geoms > kMaxGeometriesBvh)
-        return fail(FF_ERR_UNSUPPORTED, "BVH mode supports at most %d geometries (scene has %d)", kMaxGeometriesBvh, s->num_geoms);
     if (n == 0) return FF_OK;
-    if (trace_mode == FF_TRACE_BVH && bvh_block_threads(s, kBlockThreads) == 0)
-        return fail(FF_ERR_UNSUPPORTED, "ff_intersect_rays: BVH of depth %d does not fit the LDS traversal stack; use FF_TRACE_BRUTE_FORCE or a host-built tree", s->max_depth);
+    if (trace_mode == FF_TRACE_BVH && s->scene_block_threads == 0)
+        return fail(FF_ERR_UNSUPPORTED, "ff_intersect_rays: 4-wide BVH of depth %d does not fit the LDS traversal stack; use FF_TRACE_BRUTE_FORCE or a host-built tree", s->max_depth4);
     FF_HIP(hipSetDevice(s->device));
     FfRay* d_rays = nullptr;
     FfIntersect* d_out = nullptr;
@@ -917,10 +1056,10 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.num_quads = s->num_quads;
     p.geoms = s->d_geoms;
     p.tris = s->d_tris;
-    p.nodes = s->d_nodes;
-    p.stack_depth = s->max_depth + 1;
-    const int fit = max_lds_nodes(p.stack_depth, kBlockThreads, s->num_geoms);
-    p.lds_nodes = s->num_nodes < fit ? s->num_nodes : (fit > 0 ? fit : 0);
+    p.nodes4 = s->d_nodes4;
+    p.stack_depth = s->stack_entries;
+    p.tlas = s->tlas_depth > 0 ? s->d_tlas : nullptr;
+    p.lds_nodes = s->lds_cap; // (the records' LDS shares were laid out for the trace kernel's workgroup; 512 threads leave more room, never less)
     e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);

@@ -535,6 +535,67 @@ __global__ __launch_bounds__(kBuildBlock) void refit_kernel(const FfTriangle* __
     }
 }
 
+// ---- 4-wide collapse ---------------------------------------------------------------------------------------------------
+
+// flag[i] = 1 for binary nodes at even depth (they become 4-wide nodes); counters[1] = depth of the 4-wide tree.
+__global__ __launch_bounds__(kBuildBlock) void collapse_flag_kernel(int node_first, int node_count, const int* __restrict__ parent, uint32_t* __restrict__ flag,
+                                                                     int* counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_count) return;
+    int depth = 0;
+    for (int p = parent[i]; p >= 0 && depth < 4096; p = parent[(p >> 1) - node_first]) ++depth;
+    const bool even = (depth & 1) == 0;
+    flag[i] = even ? 1u : 0u;
+    if (even) atomicMax(&counters[1], depth / 2 + 1);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void collapse_emit_kernel(const BvhNode* __restrict__ nodes, int node_first, int node_count,
+                                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ index4,
+                                                                     Bvh4Node* __restrict__ nodes4, int node4_first)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_count || flag[i] == 0u) return;
+    const BvhNode nd = nodes[node_first + i];
+    Bvh4Node out;
+    int slots = 0;
+    auto add = [&](const float* mn, const float* mx, int link) {
+        for (int q = 0; q < slots; ++q)
+            if (link < 0 && out.link[q] == link) return; // a mesh that fits one leaf carries that leaf on both links
+        for (int k = 0; k < 3; ++k) {
+            out.mn[k][slots] = mn[k];
+            out.mx[k][slots] = mx[k];
+        }
+        out.link[slots] = link < 0 ? link : (int)index4[link - node_first]; // grandchildren sit at even depth: they are 4-wide nodes
+        ++slots;
+    };
+    for (int side = 0; side < 2; ++side) {
+        const int link = side == 0 ? nd.left : nd.right;
+        const float* mn = side == 0 ? nd.lmin : nd.rmin;
+        const float* mx = side == 0 ? nd.lmax : nd.rmax;
+        if (link < 0) {
+            add(mn, mx, link);
+        } else {
+            const BvhNode ch = nodes[link];
+            add(ch.lmin, ch.lmax, ch.left);
+            add(ch.rmin, ch.rmax, ch.right);
+        }
+    }
+    for (int q = slots; q < 4; ++q) {
+        for (int k = 0; k < 3; ++k) {
+            out.mn[k][q] = __builtin_huge_valf();
+            out.mx[k][q] = -__builtin_huge_valf();
+        }
+        out.link[q] = kEmptyLink;
+    }
+    nodes4[node4_first + (int)index4[i]] = out;
+}
+
+__global__ void collapse_count_kernel(int node_count, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ index4, int* counters)
+{
+    counters[0] = (int)(index4[node_count - 1] + flag[node_count - 1]);
+}
+
 // ---- scratch -----------------------------------------------------------------------------------------------------------
 
 struct Carver {
@@ -704,6 +765,44 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
     out->root = node_base;
     out->node_count = emitted;
     out->depth = depth;
+    return FF_OK;
+}
+
+int gpu_collapse_mesh(hipStream_t stream, BuildScratch& scratch, const BvhNode* d_nodes, int node_first, int node_count, const int* d_parent,
+                      Bvh4Node* d_nodes4, int node4_first, Collapse4Info* info)
+{
+    if (node_count <= 0) {
+        if (info) *info = Collapse4Info();
+        return FF_OK;
+    }
+    size_t temp_scan = 0;
+    FFB_HIP(rocprim::exclusive_scan(nullptr, temp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)node_count, rocprim::plus<uint32_t>(), stream));
+    Carver probe(nullptr);
+    probe.take<int>(8);
+    probe.take<uint32_t>((size_t)node_count);
+    probe.take<uint32_t>((size_t)node_count);
+    probe.take<char>(temp_scan);
+    int st = ensure_scratch(scratch, probe.used + 256);
+    if (st != FF_OK) return st;
+    Carver c(scratch.base);
+    int* counters = c.take<int>(8);
+    uint32_t* flag = c.take<uint32_t>((size_t)node_count);
+    uint32_t* index4 = c.take<uint32_t>((size_t)node_count);
+    void* temp = c.take<char>(temp_scan);
+    FFB_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), stream));
+    collapse_flag_kernel<<<grid_for(node_count), kBuildBlock, 0, stream>>>(node_first, node_count, d_parent, flag, counters);
+    FFB_HIP(rocprim::exclusive_scan(temp, temp_scan, flag, index4, 0u, (size_t)node_count, rocprim::plus<uint32_t>(), stream));
+    collapse_emit_kernel<<<grid_for(node_count), kBuildBlock, 0, stream>>>(d_nodes, node_first, node_count, flag, index4, d_nodes4, node4_first);
+    FFB_HIP(hipGetLastError());
+    if (info) {
+        collapse_count_kernel<<<1, 1, 0, stream>>>(node_count, flag, index4, counters);
+        int host[2] = { 0, 0 };
+        FFB_HIP(hipMemcpyAsync(host, counters, sizeof host, hipMemcpyDeviceToHost, stream));
+        FFB_HIP(hipStreamSynchronize(stream));
+        info->node_count = host[0];
+        info->depth = host[1];
+        if (host[0] < 1 || host[0] > node_count) return fail(FF_ERR_HIP, "gpu_collapse_mesh: inconsistent 4-wide node count %d for %d binary nodes", host[0], node_count);
+    }
     return FF_OK;
 }
 

@@ -54,6 +54,21 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "64-byte BVH node");
 
+// One 112-byte node of the 4-wide tree the trace kernels traverse.  It is DERIVED from the binary tree above (which stays
+// the representation the builders write and refit works on): every binary node at even depth becomes a 4-wide node whose
+// slots are its grandchildren (a child that is a leaf fills one slot), see gpu_collapse_mesh.  Seven 16-byte quarters:
+// the six box planes, each holding that coordinate for the four slots, and the four links.  A ray reads the three "near"
+// and the three "far" planes picked by the signs of its direction, so a slab test is 6 FMAs + max3 + min3.
+// link >= 0: index of a 4-wide node RELATIVE to the mesh's first one (its root is 0); link < 0: leaf, ~link =
+// (first_tri << 3) | (count - 1) as in BvhNode; kEmptyLink: unused slot (its box is inverted: +inf / -inf, never hit).
+struct Bvh4Node {
+    float mn[3][4]; // [axis][slot]
+    float mx[3][4];
+    int32_t link[4];
+};
+static_assert(sizeof(Bvh4Node) == 112, "112-byte 4-wide BVH node");
+constexpr int32_t kEmptyLink = 0x7fffffff;
+
 // Per-geometry record (wave-uniform reads in the kernel).  Matrices are stored as xyz columns.
 struct GeomRecord {
     // m_inverseModelMatrix columns 0..3 (xyz).  The w slots of columns 0..2 hold (column3 * 0.0f).xyz, the signed zero
@@ -70,10 +85,12 @@ struct GeomRecord {
     int32_t bxdf_type;                                // FfBXDFType
     int32_t tri_first;                                // first TriRecord of this mesh
     int32_t tri_count;
-    int32_t bvh_root;                                 // inner-node index of this mesh's root, -1 if none
+    int32_t bvh_root;                                 // index of this mesh's first (root) node in the BINARY node array, -1 if none
     int32_t orig_index;                               // index i in the caller's Geometry[] (kernel.cu:151,162); records are
                                                       // stored in PROCESSING order: planes first, then meshes
-    int32_t pad[2];
+    int32_t node4_first;                              // index of this mesh's root in the 4-wide node array (Bvh4Node links are relative to it)
+    int32_t lds_nodes;                                // the mesh's 4-wide nodes [0, lds_nodes) (relative) are cached in LDS by the trace kernels ...
+                                                      // ... at LDS node index lds_first + relative index; lds_first lives in the w lane of wmin (as int bits)
 };
 static_assert(sizeof(GeomRecord) == 16 * 16 + 32, "GeomRecord layout");
 
@@ -105,6 +122,12 @@ int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams&
 // Flatten host geometries into device records.  Returns an FfStatus.  build_bvh = false fills the geometry records only
 // (tri_first / tri_count assigned, bvh_root = -1, no triangle records, no nodes): the device builder's input.
 int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, CompiledScene& out, bool build_bvh = true);
+
+// Binary tree over the padded world boxes of ALL geometry records (planes, spheres and meshes; records in processing order):
+// what a query of a scene with more than 32 geometries walks instead of scanning every record (kernel.cu:133's loop).
+// nodes[0] is the root; link >= 0: node index, link < 0: ~(record index).  Median splits of the box centres along the
+// widest axis, one geometry per leaf.  Needs at least two records.  Returns the depth (nodes on the longest root-to-leaf path).
+int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes);
 
 // World-space AABB of a geometry record from object-space bounds (through the record's model matrix, padded).
 void set_world_box(GeomRecord& r, const float omn[3], const float omx[3]);

@@ -10,8 +10,9 @@ namespace ff {
 constexpr int kBlockThreads = 512;        // default workgroup: 8 waves, one workgroup per CU shares one LDS copy of the BVH top
 constexpr int kBlockThreadsMax = 1024;    // alternative: 16 waves per workgroup (4 per SIMD), smaller node cache next to the stacks
 constexpr int kLdsBudgetBytes = 160 * 1024;
-constexpr int kMaxGeometriesBvh = 128;    // BVH mode: geometry records resident in LDS (288 B each); queries work through them in chunks of 32
-                                          // (one candidate bit per record of the chunk)
+constexpr int kChunkGeometries = 32;      // BVH mode, up to this many geometries (the reference has 5): records resident in LDS (288 B each), one
+                                          // candidate bit per record; beyond it a query walks a tree over the geometries' world boxes (KParams::tlas)
+                                          // and reads the records from global memory
 constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
 
 // Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).
@@ -27,7 +28,8 @@ struct KParams {
     int strip_rows, part, num_parts, local_rows;
     int x0, y0, local_width; // window inside the image: local pixel (lx, ly) is global (x0 + lx, y0 + row of the strip layout);
                              // whole-width strips: x0 = y0 = 0, local_width = width
-    unsigned total_items; // work items of this launch: pix_items x (block_end - block_begin)
+    unsigned whole_blocks; // sample blocks this launch hands out as whole (pixel, block) items: block_end - block_begin, minus the tail block
+    unsigned total_items; // work items of this launch: pix_items x whole_blocks (+ the tail block's group items)
     int items_per_fetch;  // items a lane takes per queue fetch (1 for long items; more when an item is only a few samples)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
@@ -40,11 +42,6 @@ struct KParams {
     // BVH kernel scheduling knobs: setup_threshold = traversal time slice in inner-node rounds (0 = run every query to
     // completion before the wave shades); leaf_threshold = number of lanes holding a leaf that ends an inner-node phase early
     int setup_threshold, leaf_threshold;
-    // path-pool scheduler (null pool = time-sliced kernel): wave-private workspace of pool_slots x 28 words per wave;
-    // pool_refill = idle lanes that trigger a refill from the READY list; pool_low = running lanes below which a partial
-    // batch of FINISHED slots is set up although fewer than 64 are waiting
-    unsigned* pool;
-    int pool_slots, pool_refill, pool_low;
     // scene
     int num_geoms;
     int num_planes;  // records [0, num_planes) are analytic shapes (planes, then spheres), the rest meshes (processing order)
@@ -53,11 +50,13 @@ struct KParams {
     const GeomRecord* geoms;
     const TriRecord* tris;
     const float4* trinormals; // vertex normals (3 float4 per triangle, parallel to tris); null unless FF_SHADE_DIFFUSE_PATH_SMOOTH
-    const BvhNode* nodes;
-    int lds_nodes;   // nodes [0, lds_nodes) are staged in LDS
-    int stack_depth; // entries per lane in the LDS traversal stack
+    const Bvh4Node* nodes4; // the 4-wide trees of all meshes (each mesh's nodes contiguous, level by level, links relative to its root)
+    const BvhNode* tlas;    // scenes of more than kChunkGeometries geometries: binary tree over the geometries' padded world boxes
+                            // (node 0 = root; link >= 0: node, < 0: ~(geometry record index)); null otherwise
+    int lds_nodes;   // LDS node slots (which nodes of which mesh fill them: GeomRecord::lds_nodes / lds_first)
+    int stack_depth; // entries per lane in the LDS traversal stack (depth of the deepest 4-wide tree + 1)
     // outputs (local image: local_rows x width)
-    float4* blocksums;       // [num_blocks][pix_items] radiance sums of the sample blocks (tile-major pixel order)
+    float4* blocksums;       // [pix_items][num_blocks] radiance sums of the sample blocks (tile-major pixel order)
     unsigned char* rgb8;     // 3 bytes per local pixel, or null
     float* radiance;         // 3 floats per local pixel, or null
     unsigned* queue;         // work-item counter (zeroed before each launch)
@@ -83,7 +82,8 @@ struct RayBatchParams {
     int num_quads;
     const GeomRecord* geoms;
     const TriRecord* tris;
-    const BvhNode* nodes;
+    const Bvh4Node* nodes4;
+    const BvhNode* tlas;
     int lds_nodes;
     int stack_depth;
 };
@@ -92,8 +92,6 @@ struct RayBatchParams {
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms);
 // Largest node count that fits LDS next to a stack of `stack_depth` entries per lane.
 int max_lds_nodes(int stack_depth, int block_threads, int num_geoms);
-size_t pool_list_bytes(int pool_slots, int block_threads);
-size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads);
 
 // block_threads: 512 or 1024 for the BVH kernel; the brute-force kernel always runs 512.
 // *kernel_name (optional) receives the name of the instantiation launched, as rocprofv3 prints it.

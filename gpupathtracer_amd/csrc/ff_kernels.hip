@@ -288,82 +288,102 @@ __device__ __forceinline__ void fill_smooth_normal(const GeomRecord* __restrict_
 
 // ---- LDS layout of the BVH kernels -----------------------------------------------------------------------------------
 //
-//   [ nodes: 4 planes of lds_nodes x 16 B ][ traversal stacks: stack_depth x BLOCK x 4 B, lane-strided ][ geometry records: G x 288 B ]
+//   [ nodes: 7 planes of node_cap x 16 B ][ traversal stacks: stack_depth x BLOCK x 4 B, lane-strided ][ geometry records: G x 288 B ]
 //
 // ff_smem is indexed directly (never through a generic pointer) so that every access compiles to ds_read/ds_write.
 extern __shared__ uint4 ff_smem[];
 
 constexpr int kGeomVec4 = (int)(sizeof(GeomRecord) / 16); // 18 float4 per geometry record
+constexpr int kNodeVec4 = (int)(sizeof(Bvh4Node) / 16);   // 7 quarters per 4-wide node: six box planes + links
 constexpr int kDone = 0x7fffffff;                         // traversal cursor of a lane with nothing left to visit
+constexpr int kPackedEntry = 0x40000000;                  // stack entry that names a node and up to three of its slots (see inner_step)
 
-struct Lds {
-    int node_count; // nodes [0, node_count) live in LDS
+struct LdsBase {
+    int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j
     int stack_base; // uint index of this lane's stack slot 0 (in units of 4 bytes from ff_smem)
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
     const float4* smooth_normals; // non-null: triangle hits carry the interpolated vertex normal (FF_SHADE_DIFFUSE_PATH_SMOOTH)
     int last_base;  // first record of the last chunk of 32 geometry records: ((num_geoms - 1) / 32) * 32
+    // Scenes of more than 32 geometries ("big", a compile-time property of the kernel instantiation): the records stay in
+    // global memory (L1/L2) and a query finds its candidates by walking a tree over the geometries' world boxes (tlas).
+    const float4* geoms_g;
+    const uint4* tlas; // BvhNode array in world space; link >= 0: node, < 0: ~(geometry record index)
+};
+// (`big` is part of the TYPE, not a field: with a field the optimiser meets a select between an LDS and a global pointer in
+// the record accessors before it has folded the flag, and this compiler crashes on it.)
+template <bool BIG>
+struct LdsT : LdsBase {
+    static constexpr bool big = BIG;
 };
 
-__device__ __forceinline__ Lds make_lds(int lds_nodes, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
-                                        int last_base = 0)
+template <bool BIG = false>
+__device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
+                                              int last_base = 0, const GeomRecord* geoms = nullptr, const BvhNode* tlas = nullptr)
 {
-    Lds L;
+    LdsT<BIG> L;
+    L.geoms_g = reinterpret_cast<const float4*>(geoms);
+    L.tlas = reinterpret_cast<const uint4*>(tlas);
     L.num_quads = num_quads;
     L.smooth_normals = smooth_normals;
     L.last_base = last_base;
-    L.node_count = lds_nodes;
+    L.node_cap = node_cap;
     L.stride = block;
-    L.stack_base = lds_nodes * 16 + tid;
-    L.geom_base = lds_nodes * 4 + (stack_depth * block) / 4;
+    L.stack_base = node_cap * (kNodeVec4 * 4) + tid;
+    L.geom_base = node_cap * kNodeVec4 + (stack_depth * block) / 4;
     return L;
 }
 
-// Stage the top of the BVH and the geometry records: coalesced 16-byte loads, 1 KiB per wave-instruction.  Persistent
-// workgroups pay this once per launch, not per ray.
-__device__ __forceinline__ void stage_scene(const Lds& L, const BvhNode* __restrict__ nodes, const GeomRecord* __restrict__ geoms, int num_geoms,
-                                            int tid, int block)
+// Stage the top of every mesh's 4-wide tree and the geometry records: coalesced 16-byte loads, 1 KiB per wave-instruction.
+// Persistent workgroups pay this once per launch, not per ray.  Which nodes of which mesh are cached was decided on the
+// host (GeomRecord::lds_nodes nodes from the mesh's root on, at LDS node index lds_first: the trees are numbered level by
+// level, so that is the top of each tree).
+template <class LDS>
+__device__ __forceinline__ void stage_scene(const LDS& L, const uint4* __restrict__ nodes4, const GeomRecord* __restrict__ geoms, int num_geoms,
+                                            int num_planes, int tid, int block)
 {
-    // Nodes are stored as four planes of 16-byte quarters (quarter k of node i at uint4 index k * node_count + i): lanes
-    // fetch quarter k of unrelated nodes with one ds_read_b128, and in this layout those addresses spread over all LDS
-    // banks, whereas whole 64-byte nodes would put every lane's quarter k on the same quarter of the banks.
-    const uint4* src = reinterpret_cast<const uint4*>(nodes);
-    for (int i = tid; i < L.node_count * 4; i += block) ff_smem[(i & 3) * L.node_count + (i >> 2)] = src[i];
-    const uint4* gsrc = reinterpret_cast<const uint4*>(geoms);
-    for (int i = tid; i < num_geoms * kGeomVec4; i += block) ff_smem[L.geom_base + i] = gsrc[i];
+    // Nodes are stored as seven planes of 16-byte quarters: lanes fetch quarter k of unrelated nodes with one
+    // ds_read_b128, and in this layout those addresses spread over all LDS banks, whereas whole nodes would put every
+    // lane's quarter k on the same banks.
+    for (int g = num_planes; g < num_geoms; ++g) {
+        const int count = geoms[g].lds_nodes;
+        if (count <= 0) continue;
+        const int base = __float_as_int(geoms[g].wmin[3]);
+        const uint4* src = nodes4 + (size_t)geoms[g].node4_first * kNodeVec4;
+        for (int i = tid; i < count * kNodeVec4; i += block) {
+            const int j = i / kNodeVec4, k = i - j * kNodeVec4;
+            ff_smem[k * L.node_cap + base + j] = src[i];
+        }
+    }
+    if constexpr (!LDS::big) {
+        const uint4* gsrc = reinterpret_cast<const uint4*>(geoms);
+        for (int i = tid; i < num_geoms * kGeomVec4; i += block) ff_smem[L.geom_base + i] = gsrc[i];
+    }
     __syncthreads();
 }
 
-__device__ __forceinline__ float4 lds_geom4(const Lds& L, int g, int k)
+// Quarter k of geometry record g.
+template <class LDS>
+__device__ __forceinline__ float4 lds_geom4(const LDS& L, int g, int k)
 {
+    if constexpr (LDS::big) return L.geoms_g[(size_t)g * kGeomVec4 + k];
     return reinterpret_cast<const float4*>(ff_smem)[L.geom_base + g * kGeomVec4 + k];
 }
-__device__ __forceinline__ int4 lds_geom_i4(const Lds& L, int g, int k)
+template <class LDS>
+__device__ __forceinline__ int4 lds_geom_i4(const LDS& L, int g, int k)
 {
+    if constexpr (LDS::big) return reinterpret_cast<const int4*>(L.geoms_g)[(size_t)g * kGeomVec4 + k];
     return reinterpret_cast<const int4*>(ff_smem)[L.geom_base + g * kGeomVec4 + k];
 }
-__device__ __forceinline__ void stack_push(const Lds& L, int sp, int v) { reinterpret_cast<int*>(ff_smem)[L.stack_base + sp * L.stride] = v; }
-__device__ __forceinline__ int stack_pop(const Lds& L, int sp) { return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride]; }
-
-__device__ __forceinline__ void fetch_node(const Lds& L, const BvhNode* __restrict__ nodes, int cur, uint4& q0, uint4& q1, uint4& q2, uint4& q3)
-{
-    if (cur < L.node_count) {
-        q0 = ff_smem[cur];
-        q1 = ff_smem[cur + L.node_count];
-        q2 = ff_smem[cur + 2 * L.node_count];
-        q3 = ff_smem[cur + 3 * L.node_count];
-    } else {
-        const uint4* p = reinterpret_cast<const uint4*>(nodes) + (size_t)cur * 4;
-        q0 = p[0];
-        q1 = p[1];
-        q2 = p[2];
-        q3 = p[3];
-    }
-}
+template <class LDS>
+__device__ __forceinline__ void stack_push(const LDS& L, int sp, int v) { reinterpret_cast<int*>(ff_smem)[L.stack_base + sp * L.stride] = v; }
+template <class LDS>
+__device__ __forceinline__ int stack_pop(const LDS& L, int sp) { return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride]; }
 
 // kernel.cu:138 with the geometry record gathered from LDS by a lane-varying index (same arithmetic as object_space_ray).
-__device__ __forceinline__ void object_space_ray_lds(const Lds& L, int g, const Ray& r, Ray& o, float& len)
+template <class LDS>
+__device__ __forceinline__ void object_space_ray_lds(const LDS& L, int g, const Ray& r, Ray& o, float& len)
 {
     const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
     o.ox = (c0.x * r.ox + c1.x * r.oy) + (c2.x * r.oz + c3.x);
@@ -449,7 +469,13 @@ struct Segment {
     Pending pend;
     unsigned meshes;           // candidate meshes not started yet (bit = record index - base)
     int base;                  // first geometry record of the chunk of 32 the query is working on (0 unless the scene has > 32)
-    int cur, sp, mesh;         // traversal cursor (inner >= 0, leaf < 0, kDone), stack height, record index of the current mesh
+    int cur, sp, mesh;         // traversal cursor (4-wide node relative to the mesh's root >= 0, leaf < 0, kDone), stack height, record index of the current mesh
+    int tl_sp;                 // big scenes: stack entries [0, tl_sp) are pending nodes / geometries of the tree over the geometries;
+                               // the current mesh's entries sit above them (0 in scenes of up to 32 geometries)
+    int node_base;             // the current mesh's first node in the global 4-wide node array
+    int lds_first, lds_count;  // its nodes [0, lds_count) sit in LDS from LDS node index lds_first on
+    int pnx, pny, pnz;         // box planes (quarters of a node) the ray enters through: min planes 0/1/2 or max planes 3/4/5 by the sign of its direction
+    int pfx, pfy, pfz;         // ... and leaves through
     Ray osr;                   // object-space ray of the current mesh
     float ix, iy, iz, ox, oy, oz; // 1/d and -o/d of osr (box tests)
     float scale;               // object-space t per unit of world distance
@@ -471,7 +497,8 @@ struct HitPoint {
     float cx, cy, cz; // object-space normal as found (see Best)
 };
 
-__device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, int g, int rec, float& dist, HitPoint& H,
+template <class LDS>
+__device__ __forceinline__ bool exact_hit(const LDS& L, const TriRecord* __restrict__ tris, const Ray& wr, int g, int rec, float& dist, HitPoint& H,
                                           int& orig_tri)
 {
     Ray osr;
@@ -515,7 +542,8 @@ __device__ __forceinline__ bool exact_hit(const Lds& L, const TriRecord* __restr
 
 // Resolve the pending candidate exactly and merge it into `best` (kernel.cu:115-121).  Returns true if it became the
 // best; then H is its hit point and normal.
-__device__ __forceinline__ bool resolve_pending(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Pending& pend, BestId& best,
+template <class LDS>
+__device__ __forceinline__ bool resolve_pending(const LDS& L, const TriRecord* __restrict__ tris, const Ray& wr, Pending& pend, BestId& best,
                                                 HitPoint& H)
 {
     const int g = pend.geom, rec = pend.rec;
@@ -554,6 +582,69 @@ __device__ __forceinline__ bool offer(float d, int g, int rec, Pending& pend, co
     return false;
 }
 
+// One plane or sphere against the lane's query.  Planes are screened WITHOUT the IEEE sqrt/divide of kernel.cu:138: the hit
+// position on the unit quad does not depend on the length of the object-space direction, so the screen works on the
+// un-normalised direction M^-1*d, for which the ray parameter is the world-space parameter.  Anything within the margins
+// (quad edges, t ~ 0, |n.d| ~ 1e-7) is decided by the exact reference test at once.
+template <bool STATS, class LDS>
+__device__ __forceinline__ void screen_analytic(const LDS& L, int g, const TriRecord* __restrict__ tris, const Ray& wr, float wlen, Segment& S, Counters& cnt)
+{
+    if (STATS) { cnt.planes += 1; probe_round(cnt.plane_rounds); }
+    if (g >= L.num_quads) {
+        // spheres have no screening form: the exact test runs here and yields the approximate world distance
+        Ray osr;
+        float len;
+        object_space_ray_lds(L, g, wr, osr, len);
+        const float tt = sphere_t(lds_geom4(L, g, 11).w, osr);
+        const float sdist = tt * wlen * __builtin_amdgcn_rcpf(len);
+        if (tt > 0.0f && offer(sdist, g, -1, S.pend, S.best)) {
+            HitPoint H;
+            resolve_pending(L, tris, wr, S.pend, S.best, H);
+            offer(sdist, g, -1, S.pend, S.best);
+        }
+        return;
+    }
+    const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
+    const float4 pn = lds_geom4(L, g, 11);
+    // object-space origin and un-normalised direction (screening only: FMA form)
+    const float ox = __builtin_fmaf(c0.x, wr.ox, __builtin_fmaf(c1.x, wr.oy, __builtin_fmaf(c2.x, wr.oz, c3.x)));
+    const float oy = __builtin_fmaf(c0.y, wr.ox, __builtin_fmaf(c1.y, wr.oy, __builtin_fmaf(c2.y, wr.oz, c3.y)));
+    const float oz = __builtin_fmaf(c0.z, wr.ox, __builtin_fmaf(c1.z, wr.oy, __builtin_fmaf(c2.z, wr.oz, c3.z)));
+    const float ux = __builtin_fmaf(c0.x, wr.dx, __builtin_fmaf(c1.x, wr.dy, c2.x * wr.dz));
+    const float uy = __builtin_fmaf(c0.y, wr.dx, __builtin_fmaf(c1.y, wr.dy, c2.y * wr.dz));
+    const float uz = __builtin_fmaf(c0.z, wr.dx, __builtin_fmaf(c1.z, wr.dy, c2.z * wr.dz));
+    const float nx = pn.x, ny = pn.y, nz = pn.z;
+    const float dn = __builtin_fmaf(nx, ux, __builtin_fmaf(ny, uy, nz * uz));         // n . (M^-1 d)
+    const float num = -__builtin_fmaf(nx, ox, __builtin_fmaf(ny, oy, nz * oz));       // -(n . o')
+    const float len2 = __builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz));
+    // kernel.cu:12 |n.d'| >= 1e-7 with d' = u/len  <=>  dn^2 >= 1e-14 * len2
+    const float q = dn * dn, qlim = 1.0e-14f * len2;
+    const float ta = num * __builtin_amdgcn_rcpf(dn);                                 // world ray parameter of the plane
+    const float Pxa = __builtin_fmaf(ta, ux, ox), Pya = __builtin_fmaf(ta, uy, oy);
+    const float omag = fabsf(ox) + fabsf(oy) + fabsf(oz);
+    const float delta = 1.0e-5f * (1.0f + omag);
+    const float ex = fabsf(Pxa), ey = fabsf(Pya);
+    const bool front_sure = ta > 0.0f && fabsf(num) > 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz));
+    bool hit = ex <= 0.5f - delta && ey <= 0.5f - delta && front_sure && q >= qlim * 1.01f;
+    float dist = ta * wlen; // approximate world distance
+    if (!hit && ex <= 0.5f + delta && ey <= 0.5f + delta && q >= qlim * 0.99f && (front_sure || fabsf(num) <= 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz)))) {
+        // within a margin: decide with the exact reference test (kernel.cu:138 + :8-32)
+        if (STATS) cnt.plane_exact += 1;
+        Ray osr;
+        float len;
+        object_space_ray_lds(L, g, wr, osr, len);
+        const float tt = plane_t(nx, ny, nz, osr);
+        hit = tt > 0.0f;
+        dist = tt * wlen * __builtin_amdgcn_rcpf(len);
+    }
+    if (hit && offer(dist, g, -1, S.pend, S.best)) {
+        // two planes too close to rank approximately (a ray into an edge of the box): settle the held one exactly
+        HitPoint H;
+        resolve_pending(L, tris, wr, S.pend, S.best, H);
+        offer(dist, g, -1, S.pend, S.best);
+    }
+}
+
 // Start a closest-hit query: test every plane (fast form) and remember which meshes the ray can reach.
 //
 // Planes are screened in a wave-uniform loop (records through scalar loads, all lanes busy) WITHOUT the IEEE sqrt/divide
@@ -563,8 +654,8 @@ __device__ __forceinline__ bool offer(float d, int g, int rec, Pending& pend, co
 // One chunk of up to 32 geometry records starting at S.base: screen its planes / spheres and collect its candidate meshes.
 // Scenes of up to 32 geometries (the reference has 5) are a single chunk; larger scenes are worked through chunk by chunk,
 // each query carrying its best / pending candidate across chunks.
-template <bool STATS>
-__device__ __forceinline__ void scan_chunk(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+template <bool STATS, class LDS>
+__device__ __forceinline__ void scan_chunk(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                            const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
     const int base = S.base;
@@ -587,60 +678,7 @@ __device__ __forceinline__ void scan_chunk(const Lds& L, const GeomRecord* __res
         if (quads == 0u) continue;
         const int g = base + __ffs((int)quads) - 1;
         quads &= quads - 1u;
-        if (STATS) { cnt.planes += 1; probe_round(cnt.plane_rounds); }
-        if (g >= L.num_quads) {
-            // spheres have no screening form: the exact test runs here and yields the approximate world distance
-            Ray osr;
-            float len;
-            object_space_ray_lds(L, g, wr, osr, len);
-            const float tt = sphere_t(lds_geom4(L, g, 11).w, osr);
-            const float sdist = tt * wlen * __builtin_amdgcn_rcpf(len);
-            if (tt > 0.0f && offer(sdist, g, -1, S.pend, S.best)) {
-                HitPoint H;
-                resolve_pending(L, tris, wr, S.pend, S.best, H);
-                offer(sdist, g, -1, S.pend, S.best);
-            }
-            continue;
-        }
-        const float4 c0 = lds_geom4(L, g, 0), c1 = lds_geom4(L, g, 1), c2 = lds_geom4(L, g, 2), c3 = lds_geom4(L, g, 3);
-        const float4 pn = lds_geom4(L, g, 11);
-        // object-space origin and un-normalised direction (screening only: FMA form)
-        const float ox = __builtin_fmaf(c0.x, wr.ox, __builtin_fmaf(c1.x, wr.oy, __builtin_fmaf(c2.x, wr.oz, c3.x)));
-        const float oy = __builtin_fmaf(c0.y, wr.ox, __builtin_fmaf(c1.y, wr.oy, __builtin_fmaf(c2.y, wr.oz, c3.y)));
-        const float oz = __builtin_fmaf(c0.z, wr.ox, __builtin_fmaf(c1.z, wr.oy, __builtin_fmaf(c2.z, wr.oz, c3.z)));
-        const float ux = __builtin_fmaf(c0.x, wr.dx, __builtin_fmaf(c1.x, wr.dy, c2.x * wr.dz));
-        const float uy = __builtin_fmaf(c0.y, wr.dx, __builtin_fmaf(c1.y, wr.dy, c2.y * wr.dz));
-        const float uz = __builtin_fmaf(c0.z, wr.dx, __builtin_fmaf(c1.z, wr.dy, c2.z * wr.dz));
-        const float nx = pn.x, ny = pn.y, nz = pn.z;
-        const float dn = __builtin_fmaf(nx, ux, __builtin_fmaf(ny, uy, nz * uz));         // n . (M^-1 d)
-        const float num = -__builtin_fmaf(nx, ox, __builtin_fmaf(ny, oy, nz * oz));       // -(n . o')
-        const float len2 = __builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz));
-        // kernel.cu:12 |n.d'| >= 1e-7 with d' = u/len  <=>  dn^2 >= 1e-14 * len2
-        const float q = dn * dn, qlim = 1.0e-14f * len2;
-        const float ta = num * __builtin_amdgcn_rcpf(dn);                                 // world ray parameter of the plane
-        const float Pxa = __builtin_fmaf(ta, ux, ox), Pya = __builtin_fmaf(ta, uy, oy);
-        const float omag = fabsf(ox) + fabsf(oy) + fabsf(oz);
-        const float delta = 1.0e-5f * (1.0f + omag);
-        const float ex = fabsf(Pxa), ey = fabsf(Pya);
-        const bool front_sure = ta > 0.0f && fabsf(num) > 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz));
-        bool hit = ex <= 0.5f - delta && ey <= 0.5f - delta && front_sure && q >= qlim * 1.01f;
-        float dist = ta * wlen; // approximate world distance
-        if (!hit && ex <= 0.5f + delta && ey <= 0.5f + delta && q >= qlim * 0.99f && (front_sure || fabsf(num) <= 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz)))) {
-            // within a margin: decide with the exact reference test (kernel.cu:138 + :8-32)
-            if (STATS) cnt.plane_exact += 1;
-            Ray osr;
-            float len;
-            object_space_ray_lds(L, g, wr, osr, len);
-            const float tt = plane_t(nx, ny, nz, osr);
-            hit = tt > 0.0f;
-            dist = tt * wlen * __builtin_amdgcn_rcpf(len);
-        }
-        if (hit && offer(dist, g, -1, S.pend, S.best)) {
-            // two planes too close to rank approximately (a ray into an edge of the box): settle the held one exactly
-            HitPoint H;
-            resolve_pending(L, tris, wr, S.pend, S.best, H);
-            offer(dist, g, -1, S.pend, S.best);
-        }
+        screen_analytic<STATS>(L, g, tris, wr, wlen, S, cnt);
     }
 
     if (STATS) tb2 = __builtin_amdgcn_s_memtime();
@@ -659,8 +697,8 @@ __device__ __forceinline__ void scan_chunk(const Lds& L, const GeomRecord* __res
 }
 
 // Start a closest-hit query: empty candidate slots, then the first chunk of geometry records.
-template <bool STATS>
-__device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+template <bool STATS, class LDS>
+__device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                               const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
     S.best.dist = kInf; // kernel.cu:131
@@ -671,9 +709,18 @@ __device__ __forceinline__ void begin_segment(const Lds& L, const GeomRecord* __
     S.pend.rec = -1;
     S.cur = kDone;
     S.sp = 0;
+    S.tl_sp = 0;
     S.mesh = -1;
     S.resume = 0;
     S.base = 0;
+    if constexpr (LDS::big) {
+        // big scenes: the query starts at the root of the tree over the geometries (advance_top walks it)
+        S.meshes = 0u;
+        stack_push(L, 0, 0);
+        S.tl_sp = 1;
+        S.sp = 1;
+        return;
+    }
     scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
 }
 
@@ -684,24 +731,59 @@ __device__ __forceinline__ void refresh_tbound(Segment& S)
     S.tbound = (fminf(S.best.dist, S.pend.dist) * 1.001f + 1.0e-3f) * S.scale * 1.00001f;
 }
 
-// Take the next subtree off the lane's stack.
-__device__ __forceinline__ void pop_subtree(const Lds& L, Segment& S)
+// The links of a node are needed only after its box tests.  Left alone, the compiler merges the LDS load and the global load
+// of the two branches into one load through a generic pointer placed after the tests: four flat_load_dword.  Pinning the
+// loaded value inside each branch keeps them ds_read_b128 / global_load_dwordx4.
+#define FF_PIN4(q) asm volatile("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
+
+// q[c] for a lane-varying c in 0..3 without control flow (the compiler turns a ?: chain on c into nested branches): two
+// sign-extended bit fields as masks and three bit-field inserts.
+__device__ __forceinline__ int select_slot(const uint4 q, int c)
 {
-    if (S.sp > 0) {
-        --S.sp;
-        S.cur = stack_pop(L, S.sp);
-    } else {
+    const unsigned m0 = (unsigned)((c << 31) >> 31), m1 = (unsigned)((c << 30) >> 31); // all ones where bit 0 / bit 1 of c is set
+    const unsigned lo = (q.y & m0) | (q.x & ~m0), hi = (q.w & m0) | (q.z & ~m0);
+    return (int)((hi & m1) | (lo & ~m1));
+}
+
+// Take the next subtree off the lane's stack.  An entry is a link (the common case: one sibling was pending) or names a
+// node and two or three of its slots, nearest first (kPackedEntry | node << 8 | slots << 2 | count): then the node's link
+// quarter is read again, the nearest slot becomes the cursor and the entry is rewritten for the rest.  One entry per
+// visited node bounds the stack by the depth of the tree.
+template <class LDS>
+__device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restrict__ nodes4, Segment& S)
+{
+    if (S.sp == (LDS::big ? S.tl_sp : 0)) { // nothing of the current mesh is left (below: pending entries of the top-level tree)
         S.cur = kDone;
+        return;
+    }
+    const int e = stack_pop(L, S.sp - 1);
+    if (e >= 0 && (e & kPackedEntry) != 0) {
+        const int node = (e >> 8) & 0x3FFFFF;
+        uint4 lk;
+        if ((unsigned)node < (unsigned)S.lds_count) {
+            lk = ff_smem[S.lds_first + node + 6 * L.node_cap];
+            FF_PIN4(lk);
+        } else {
+            lk = nodes4[(size_t)(S.node_base + node) * kNodeVec4 + 6];
+            FF_PIN4(lk);
+        }
+        S.cur = select_slot(lk, (e >> 2) & 3);
+        const int rest = (e & 3) == 2 ? select_slot(lk, (e >> 4) & 3)                // one slot left: its link
+                                      : ((e & ~0xFF) | (((e >> 4) & 0xF) << 2) | 2); // two left
+        stack_push(L, S.sp - 1, rest);
+    } else {
+        S.cur = e;
+        --S.sp;
     }
 }
 
-// Idle lane with candidate meshes left: enter the next one.
-__device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Segment& S)
+// Put the lane's cursor on the root of mesh g's tree: object-space ray (kernel.cu:138), slab constants, box planes by the
+// signs of the direction.
+template <class LDS>
+__device__ __forceinline__ void enter_mesh(const LDS& L, int g, const Ray& wr, Segment& S)
 {
-    const int g = S.base + __ffs((int)S.meshes) - 1;
-    S.meshes &= S.meshes - 1u;
-    const int root = lds_geom_i4(L, g, 17).x;
-    if (root < 0) return;
+    const int4 tree = lds_geom_i4(L, g, 17); // bvh_root, orig_index, node4_first, lds_nodes
+    if (tree.x < 0) return;
     float len;
     object_space_ray_lds(L, g, wr, S.osr, len);
     S.ix = safe_rcp(S.osr.dx);
@@ -710,51 +792,155 @@ __device__ __forceinline__ void start_next_mesh(const Lds& L, const Ray& wr, Seg
     S.ox = -S.osr.ox * S.ix;
     S.oy = -S.osr.oy * S.iy;
     S.oz = -S.osr.oz * S.iz;
+    S.pnx = S.ix < 0.0f ? 3 : 0;
+    S.pny = S.iy < 0.0f ? 4 : 1;
+    S.pnz = S.iz < 0.0f ? 5 : 2;
+    S.pfx = 3 - S.pnx;
+    S.pfy = 5 - S.pny;
+    S.pfz = 7 - S.pnz;
     S.scale = len * inv_length(wr); // object-space t per unit of world distance
     refresh_tbound(S);
     S.mesh = g;
-    S.cur = root;
-    S.sp = 0;
+    S.node_base = tree.z;
+    S.lds_count = tree.w;
+    S.lds_first = __float_as_int(lds_geom4(L, g, 14).w);
+    S.cur = 0;
+    S.sp = LDS::big ? S.tl_sp : 0;
 }
 
-// One inner-node visit: test both child boxes, descend to the nearer hit child, push the other, or pop.
-template <bool STATS>
-__device__ __forceinline__ void inner_step(const Lds& L, const BvhNode* __restrict__ nodes, Segment& S, Counters& cnt)
+// Idle lane with candidate meshes left: enter the next one.
+template <class LDS>
+__device__ __forceinline__ void start_next_mesh(const LDS& L, const Ray& wr, Segment& S)
 {
-    uint4 q0, q1, q2, q3;
-    fetch_node(L, nodes, S.cur, q0, q1, q2, q3);
+    const int g = S.base + __ffs((int)S.meshes) - 1;
+    S.meshes &= S.meshes - 1u;
+    enter_mesh(L, g, wr, S);
+}
+
+// Big scenes: one step of the walk through the tree over the geometries' world boxes for an idle lane (S.cur == kDone,
+// S.tl_sp > 0).  An inner node pushes the children the ray can still reach (nearer one on top); a plane or sphere is
+// screened at once; a mesh becomes the lane's current mesh.  Everything is pruned against the best / pending distance
+// the lane holds NOW (front to back, so most of a crowded scene is never looked at): kernel.cu:133's loop over all
+// geometries with the same result.
+template <bool STATS, class LDS>
+__device__ __forceinline__ void advance_top(const LDS& L, int num_planes, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+{
+    --S.tl_sp;
+    S.sp = S.tl_sp;
+    const int e = stack_pop(L, S.tl_sp);
+    const WorldSlab ws = make_world_slab(wr);
+    const float limit = fminf(S.best.dist, S.pend.dist);
+    if (e >= 0) {
+        const uint4* nd = L.tlas + (size_t)e * 4;
+        const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3]; // lmin|left, lmax|right, rmin, rmax
+        const float bound = (limit * 1.001f + 1.0e-3f) * ws.inv_len * 1.00001f;
+        float a0 = __builtin_fmaf(__uint_as_float(q0.x), ws.ix, ws.ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), ws.ix, ws.ox);
+        float b0 = __builtin_fmaf(__uint_as_float(q0.y), ws.iy, ws.oy), b1 = __builtin_fmaf(__uint_as_float(q1.y), ws.iy, ws.oy);
+        float c0 = __builtin_fmaf(__uint_as_float(q0.z), ws.iz, ws.oz), c1 = __builtin_fmaf(__uint_as_float(q1.z), ws.iz, ws.oz);
+        const float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+        const float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), bound));
+        a0 = __builtin_fmaf(__uint_as_float(q2.x), ws.ix, ws.ox); a1 = __builtin_fmaf(__uint_as_float(q3.x), ws.ix, ws.ox);
+        b0 = __builtin_fmaf(__uint_as_float(q2.y), ws.iy, ws.oy); b1 = __builtin_fmaf(__uint_as_float(q3.y), ws.iy, ws.oy);
+        c0 = __builtin_fmaf(__uint_as_float(q2.z), ws.iz, ws.oz); c1 = __builtin_fmaf(__uint_as_float(q3.z), ws.iz, ws.oz);
+        const float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+        const float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), bound));
+        const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
+        const int left = (int)q0.w, right = (int)q1.w;
+        const bool swap = hl && hr && rn < ln; // the nearer child goes on top
+        if (hl && hr) {
+            stack_push(L, S.tl_sp, swap ? left : right);
+            stack_push(L, S.tl_sp + 1, swap ? right : left);
+            S.tl_sp += 2;
+        } else if (hl || hr) {
+            stack_push(L, S.tl_sp, hl ? left : right);
+            S.tl_sp += 1;
+        }
+        S.sp = S.tl_sp;
+        return;
+    }
+    const int g = ~e;
+    // the candidate distances may have shrunk since the entry was pushed: test the geometry's own box once more
+    const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
+    if (!slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) return;
+    if (g < num_planes) {
+        const float wlen = __builtin_amdgcn_rcpf(inv_length(wr));
+        screen_analytic<STATS>(L, g, tris, wr, wlen, S, cnt);
+    } else {
+        enter_mesh(L, g, wr, S);
+    }
+}
+
+// One visit of a 4-wide node: test the four slot boxes, descend into the nearest hit, leave the others on the stack
+// (nearest on top), or pop.  Pruning only: FMA + approximate 1/d on padded boxes with inflated bounds.
+template <bool STATS, class LDS>
+__device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict__ nodes4, Segment& S, Counters& cnt)
+{
+    const int rel = S.cur;
+    uint4 nx, ny, nz, fx, fy, fz, lk;
+    if ((unsigned)rel < (unsigned)S.lds_count) {
+        const int j = S.lds_first + rel;
+        nx = ff_smem[j + S.pnx * L.node_cap];
+        ny = ff_smem[j + S.pny * L.node_cap];
+        nz = ff_smem[j + S.pnz * L.node_cap];
+        fx = ff_smem[j + S.pfx * L.node_cap];
+        fy = ff_smem[j + S.pfy * L.node_cap];
+        fz = ff_smem[j + S.pfz * L.node_cap];
+        lk = ff_smem[j + 6 * L.node_cap];
+        FF_PIN4(lk);
+    } else {
+        const uint4* p = nodes4 + (size_t)(S.node_base + rel) * kNodeVec4;
+        nx = p[S.pnx];
+        ny = p[S.pny];
+        nz = p[S.pnz];
+        fx = p[S.pfx];
+        fy = p[S.pfy];
+        fz = p[S.pfz];
+        lk = p[6];
+        FF_PIN4(lk);
+    }
     if (STATS) { cnt.nodes += 1; probe_round(cnt.inner_rounds); }
     const float tbound = S.tbound;
-    // left box: q0.xyz = min, q1.xyz = max; right box: q2.xyz = min, q3.xyz = max (pruning only: FMA + approximate 1/d)
-    float a0 = __builtin_fmaf(__uint_as_float(q0.x), S.ix, S.ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), S.ix, S.ox);
-    float b0 = __builtin_fmaf(__uint_as_float(q0.y), S.iy, S.oy), b1 = __builtin_fmaf(__uint_as_float(q1.y), S.iy, S.oy);
-    float c0 = __builtin_fmaf(__uint_as_float(q0.z), S.iz, S.oz), c1 = __builtin_fmaf(__uint_as_float(q1.z), S.iz, S.oz);
-    const float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-    const float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
-    a0 = __builtin_fmaf(__uint_as_float(q2.x), S.ix, S.ox); a1 = __builtin_fmaf(__uint_as_float(q3.x), S.ix, S.ox);
-    b0 = __builtin_fmaf(__uint_as_float(q2.y), S.iy, S.oy); b1 = __builtin_fmaf(__uint_as_float(q3.y), S.iy, S.oy);
-    c0 = __builtin_fmaf(__uint_as_float(q2.z), S.iz, S.oz); c1 = __builtin_fmaf(__uint_as_float(q3.z), S.iz, S.oz);
-    const float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-    const float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tbound));
-    const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
-    const int left = (int)q0.w, right = (int)q1.w;
-    // Two short predicated regions instead of a four-way branch: the next node is a select; only the push (both hit) and
-    // the pop (none hit) touch LDS.
-    const bool both = hl && hr, swap = both && rn < ln;
-    const int next = (hl && !swap) ? left : right; // left if it is hit and not the farther of two hits, else right
-    if (both) {
-        stack_push(L, S.sp, swap ? left : right);
+    // slot c: entry parameter = the latest of the three near planes (and 0), exit = the earliest of the far planes (and the
+    // pruning bound).  A hit slot sorts by its entry parameter: the key keeps the parameter's bits (non-negative floats
+    // order like unsigned integers) with the slot number in the two low bits; a missed slot gets the largest key.
+#define FF_SLOT_KEY(c, id)                                                                                                                       \
+    ([&]() -> unsigned {                                                                                                                         \
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(__uint_as_float(nx.c), S.ix, S.ox), __builtin_fmaf(__uint_as_float(ny.c), S.iy, S.oy)),      \
+                               fmaxf(__builtin_fmaf(__uint_as_float(nz.c), S.iz, S.oz), 0.0f));                                                  \
+        const float tf = fminf(fminf(__builtin_fmaf(__uint_as_float(fx.c), S.ix, S.ox), __builtin_fmaf(__uint_as_float(fy.c), S.iy, S.oy)),      \
+                               fminf(__builtin_fmaf(__uint_as_float(fz.c), S.iz, S.oz), tbound));                                                \
+        return tn <= tf * 1.000002f ? ((__float_as_uint(tn) & ~3u) | (unsigned)(id)) : 0xFFFFFFFFu;                                              \
+    }())
+    unsigned k0 = FF_SLOT_KEY(x, 0), k1 = FF_SLOT_KEY(y, 1), k2 = FF_SLOT_KEY(z, 2), k3 = FF_SLOT_KEY(w, 3);
+#undef FF_SLOT_KEY
+    // five-comparator sorting network: k0 <= k1 <= k2 <= k3
+    unsigned lo, hi;
+    lo = min(k0, k1); hi = max(k0, k1); k0 = lo; k1 = hi;
+    lo = min(k2, k3); hi = max(k2, k3); k2 = lo; k3 = hi;
+    lo = min(k0, k2); hi = max(k0, k2); k0 = lo; k2 = hi;
+    lo = min(k1, k3); hi = max(k1, k3); k1 = lo; k3 = hi;
+    lo = min(k1, k2); hi = max(k1, k2); k1 = lo; k2 = hi;
+    // Straight-line selects (the lanes of a wave disagree on every one of these cases): the nearest slot's link, and the
+    // entry for the siblings to come back to: one -> its link; more -> the node and their slots, nearest first.
+    const int near_link = select_slot(lk, (int)(k0 & 3u));
+    const int second_link = select_slot(lk, (int)(k1 & 3u));
+    const int packed = (int)((unsigned)kPackedEntry | ((unsigned)rel << 8) | ((k3 & 3u) << 6) | ((k2 & 3u) << 4) | ((k1 & 3u) << 2) |
+                             (k3 != 0xFFFFFFFFu ? 3u : 2u));
+    const int entry = k2 == 0xFFFFFFFFu ? second_link : packed;
+    if (k1 != 0xFFFFFFFFu) {
+        stack_push(L, S.sp, entry);
         ++S.sp;
     }
-    if (hl || hr) S.cur = next;
-    else pop_subtree(L, S);
+    if (k0 != 0xFFFFFFFFu) S.cur = near_link;
+    else pop_subtree(L, nodes4, S);
 }
 
 // One leaf visit: test the leaf's triangles (fast form), then take the next entry off the stack.  On a near tie with the
 // pending candidate the leaf is left under the cursor with S.resume set; the caller resolves the pending candidate and
 // the leaf continues from the triangle that met the tie.
-template <bool STATS>
-__device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+template <bool STATS, class LDS>
+__device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr, Segment& S,
+                                          Counters& cnt)
 {
     const int ref = ~S.cur;
     const int first = ref >> 3, count = (ref & 7) + 1;
@@ -800,12 +986,13 @@ __device__ __forceinline__ void leaf_step(const Lds& L, const TriRecord* __restr
     }
     refresh_tbound(S);
     if (S.resume > 0) return;
-    pop_subtree(L, S);
+    pop_subtree(L, nodes4, S);
 }
 
 // Settle what is still pending (the common case: the one exact evaluation of the ray, all hitting lanes together) and
 // produce the hit point of the winner.
-__device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Best& best)
+template <class LDS>
+__device__ __forceinline__ void finish_segment(const LDS& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Best& best)
 {
     bool have_point = false;
     HitPoint H = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
@@ -824,22 +1011,32 @@ __device__ __forceinline__ void finish_segment(const Lds& L, const TriRecord* __
 }
 
 // Nothing left to do in the current chunk of geometry records / in the whole query.
-__device__ __forceinline__ bool chunk_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
-__device__ __forceinline__ bool segment_done(const Lds& L, const Segment& S) { return chunk_done(S) && S.base >= L.last_base; }
+__device__ __forceinline__ bool chunk_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0 && S.tl_sp == 0; }
+template <class LDS>
+__device__ __forceinline__ bool segment_done(const LDS& L, const Segment& S) { return chunk_done(S) && S.base >= L.last_base; }
 
 // Advance the queries of the calling lanes: mesh starts, inner-node phases, leaf phases and near-tie resolutions alternate
 // wave-wide until every calling lane is done or `budget` inner-node rounds have been spent (budget <= 0: no limit).
 // Unfinished lanes keep their state in S and continue on the next call.
-template <bool STATS>
-__device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
-                                                Segment& S, Counters& cnt, int budget, int leaf_threshold)
+template <bool STATS, class LDS>
+__device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr,
+                                                Segment& S, Counters& cnt, int budget, int leaf_threshold, int num_planes = 0)
 {
     const int limit = budget > 0 ? budget : kLoopGuard;
     int rounds = 0, guard = 0;
     for (;;) {
         unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
         if (STATS) ta = __builtin_amdgcn_s_memtime();
-        while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
+        if constexpr (LDS::big) {
+            // idle lanes walk the tree over the geometries until each holds a mesh or has run out of candidates
+            for (int top = 0; top < kLoopGuard; ++top) {
+                const bool idle = S.cur == kDone && S.tl_sp > 0;
+                if (__ballot(idle) == 0ull) break;
+                if (idle) advance_top<STATS>(L, num_planes, tris, wr, S, cnt);
+            }
+        } else {
+            while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
+        }
         if (STATS) tb = __builtin_amdgcn_s_memtime();
         if (__ballot(S.cur != kDone) == 0ull) break;
         for (;;) {
@@ -849,10 +1046,10 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
             if (__popcll(__ballot(S.cur < 0)) >= leaf_threshold) break;
             if (rounds >= limit) break;
             ++rounds;
-            if (inner) inner_step<STATS>(L, nodes, S, cnt);
+            if (inner) inner_step<STATS>(L, nodes4, S, cnt);
         }
         if (STATS) tc = __builtin_amdgcn_s_memtime();
-        if (S.cur < 0) leaf_step<STATS>(L, tris, wr, S, cnt);
+        if (S.cur < 0) leaf_step<STATS>(L, tris, nodes4, wr, S, cnt);
         if (STATS) {
             td = __builtin_amdgcn_s_memtime();
             if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_start += tb - ta; cnt.t_inner += tc - tb; cnt.t_leaf += td - tc; }
@@ -870,19 +1067,19 @@ __device__ __forceinline__ void traverse_budget(const Lds& L, const TriRecord* _
 }
 
 // A complete closest-hit query for every calling lane (ray-batch kernel).
-template <bool STATS>
-__device__ __forceinline__ void closest_hit_deferred(const Lds& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
-                                                     const TriRecord* __restrict__ tris, const BvhNode* __restrict__ nodes, const Ray& wr,
+template <bool STATS, class LDS>
+__device__ __forceinline__ void closest_hit_deferred(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+                                                     const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr,
                                                      Best& best, Counters& cnt)
 {
     Segment S;
     if (STATS) probe_round(cnt.segment_rounds);
     begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
-    traverse_budget<STATS>(L, tris, nodes, wr, S, cnt, 0, 64);
+    traverse_budget<STATS>(L, tris, nodes4, wr, S, cnt, 0, 64, num_planes);
     while (S.base < L.last_base) { // > 32 geometries: the remaining chunks of records (uniform: every lane walks all chunks)
         S.base += 32;
         scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
-        traverse_budget<STATS>(L, tris, nodes, wr, S, cnt, 0, 64);
+        traverse_budget<STATS>(L, tris, nodes4, wr, S, cnt, 0, 64);
     }
     finish_segment(L, tris, wr, S, best);
     cnt.rays += 1;
@@ -944,19 +1141,19 @@ __device__ __forceinline__ void closest_hit_brute(const GeomRecord* __restrict__
 // global one.
 struct MaterialRef {
     const GeomRecord* global; // non-null: read the global record
-    Lds lds;                  // else: LDS copy
+    int geom_base;            // else: the LDS copy (uint4 index of record 0, Lds::geom_base)
     int g;
 };
 
 __device__ __forceinline__ float4 mat_f4(const MaterialRef& M, int k)
 {
     if (M.global) return reinterpret_cast<const float4*>(M.global)[k];
-    return lds_geom4(M.lds, M.g, k);
+    return reinterpret_cast<const float4*>(ff_smem)[M.geom_base + M.g * kGeomVec4 + k];
 }
 __device__ __forceinline__ int mat_bxdf(const MaterialRef& M)
 {
     if (M.global) return M.global->bxdf_type;
-    return lds_geom_i4(M.lds, M.g, 16).y;
+    return reinterpret_cast<const int4*>(ff_smem)[M.geom_base + M.g * kGeomVec4 + 16].y;
 }
 
 // `unit_object_normal`: normalise a triangle's face normal in object space first (kernel.cu:101, what Intersect::m_normal
@@ -1123,10 +1320,19 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
             } else {
                 // an item is one sample block of one pixel; pixels walk 8x8 tiles of the local image (padding items and
                 // untraced pixels are consumed and skipped), blocks are the slow index
-                // items [0, tail_first_item): (pixel, whole block); beyond: (pixel, sample group) of the tail block, group-major
+                // items [0, tail_first_item): (pixel, whole block), PIXEL-major: a wave's fetch covers the blocks of a few
+                // pixels, whose sums are neighbours in blocksums[pixel][block] and leave the XCD's L2 as whole lines instead of
+                // one masked 64-byte write per 16-byte sum; beyond: (pixel, sample group) of the tail block, group-major
                 const bool tail = p.tail_block >= 0 && item >= p.tail_first_item;
                 const unsigned rel = tail ? item - p.tail_first_item : item;
-                const unsigned blk = rel / p.pix_items, pitem = rel - blk * p.pix_items; // tail: blk is the group index
+                unsigned blk, pitem; // tail: blk is the group index
+                if (tail) {
+                    blk = rel / p.pix_items;
+                    pitem = rel - blk * p.pix_items;
+                } else {
+                    pitem = rel / p.whole_blocks;
+                    blk = rel - pitem * p.whole_blocks;
+                }
                 const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
                 const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
                 const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
@@ -1143,7 +1349,7 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                         P.send = min(p.spp_total, p.tail_block * p.block_spp + past);
                     } else {
                         const int block = p.block_begin + (int)blk;
-                        P.bitem = block * (int)p.pix_items + (int)pitem;
+                        P.bitem = (int)pitem * p.num_blocks + block;
                         P.s = block * p.block_spp;
                         P.send = min(p.spp_total, P.s + p.block_spp);
                     }
@@ -1348,14 +1554,17 @@ __device__ __forceinline__ void init_path(Path& P)
 // EXTRAS = false is the instantiation for scenes made of what the reference itself renders (planes and meshes, diffuse
 // and emitting surfaces): the plane/sphere boundary becomes a compile-time "never" and the MIRROR / GLASS branches of the
 // shader drop out (together they cost the reference-like scenes 3.5 % otherwise, measured on one box).
-template <bool STATS, int BLOCK, bool EXTRAS>
+// BIG = true (with EXTRAS) is the instantiation for scenes of more than 32 geometries: records read from global memory,
+// candidates found by walking the tree over the geometries (advance_top) instead of scanning all records.
+template <bool STATS, int BLOCK, bool EXTRAS, bool BIG = false>
 __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
-                           EXTRAS ? ((p.num_geoms - 1) >> 5) << 5 : 0);
-    stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
+    const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
+                                      EXTRAS && !BIG ? ((p.num_geoms - 1) >> 5) << 5 : 0, p.geoms, p.tlas);
+    const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
+    stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, BLOCK);
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Path P;
@@ -1370,6 +1579,8 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.scale = 1.f;
     S.tbound = 0.f;
     S.base = 0;
+    S.node_base = 0; S.lds_first = 0; S.lds_count = 0; S.tl_sp = 0;
+    S.pnx = 0; S.pny = 1; S.pnz = 2; S.pfx = 3; S.pfy = 4; S.pfz = 5;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
@@ -1396,8 +1607,8 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
         if (setup && inflight) {
             MaterialRef M;
-            M.global = nullptr;
-            M.lds = L;
+            M.global = BIG ? p.geoms + (hit ? best.geom : 0) : nullptr;
+            M.geom_base = L.geom_base;
             M.g = best.geom;
             active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
             inflight = false;
@@ -1419,7 +1630,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (__ballot(inflight) == 0ull) break;
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
         // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
-        if (inflight) traverse_budget<STATS>(L, p.tris, p.nodes, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold);
+        if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes);
         if (STATS) {
             const unsigned long long t5 = __builtin_amdgcn_s_memtime();
             tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3; tphase[4] += t5 - t4;
@@ -1434,195 +1645,6 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         atomicMax(&p.counters[22], tphase[0] + tphase[1] + tphase[2] + tphase[3] + tphase[4]); // slowest wave
         atomicMax(&p.counters[24], ~(unsigned long long)wave_t0); // (complemented) first wave start, 100 MHz wall clock
         atomicMax(&p.counters[25], (unsigned long long)wall_clock64()); // last wave end
-    }
-    flush_counters(p, lane, cnt, STATS);
-}
-
-// ---- the BVH mega-kernel with a wave-private path pool ---------------------------------------------------------------
-//
-// The time-sliced kernel above still runs its two halves at partial occupancy: after a slice only the finished lanes
-// shade (~50 %), and during a slice the finished lanes idle (~30 %).  Here every wave owns a POOL of P path slots
-// (P = 3 x 64) whose state lives in a wave-private global workspace (112 B per slot, slot-major so that 64 consecutive
-// slots are one coalesced access; it stays L2 / Infinity-Cache resident) and works in two kinds of steps:
-//
-//   S (setup)     64 lanes take 64 FINISHED slots: resolve the hit exactly, shade, spawn the next ray (or fetch a new
-//                 pixel), screen the planes and the mesh boxes, and file the slot as READY (needs BVH traversal) or
-//                 FINISHED again (planes only).  All lanes busy.
-//   T (traverse)  lanes run BVH traversal for the slot they hold; a lane whose query completes writes the outcome to
-//                 its slot, files it as FINISHED and immediately takes another READY slot, so the traversal loops stay
-//                 populated although per-ray traversal cost is heavy-tailed.  A lane in the middle of a long query
-//                 simply keeps its registers and LDS stack across S steps.
-//
-// The slot lists (READY / FINISHED) are wave-private arrays in LDS; only the owning wave touches its pool, so no atomics
-// or barriers are involved.  Results are unchanged: a slot owns its pixel for all samples (sequential accumulation), the
-// RNG is counter-based, and every hit is resolved with the exact reference arithmetic.
-
-enum PoolWord : int {
-    kRayO = 0, kRayD = 3, kBeta = 6, kAcc = 9, kBitem = 12, kGxy = 13, kSb = 14,
-    kPendDist = 15, kPendGeom = 16, kPendRec = 17, kMeshes = 18, kBestDist = 19, kBestGeom = 20, kBestRec = 21, kFlags = 22, kSend = 23, kPrimD = 24,
-    kPoolWords = 28
-};
-constexpr unsigned kSlotHasQuery = 1u, kSlotAlive = 2u;
-
-struct Pool {
-    unsigned* base; // this wave's workspace: word k of slot j at base[k * slots + j]
-    int slots;
-};
-__device__ __forceinline__ float pool_f(const Pool& W, int j, int k) { return __uint_as_float(W.base[k * W.slots + j]); }
-__device__ __forceinline__ unsigned pool_u(const Pool& W, int j, int k) { return W.base[k * W.slots + j]; }
-__device__ __forceinline__ void pool_set_f(const Pool& W, int j, int k, float v) { W.base[k * W.slots + j] = __float_as_uint(v); }
-__device__ __forceinline__ void pool_set_u(const Pool& W, int j, int k, unsigned v) { W.base[k * W.slots + j] = v; }
-
-template <bool STATS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
-{
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wave = tid >> 6;
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, BLOCK, tid, p.num_quads, p.trinormals);
-    stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, BLOCK);
-
-    const int P = p.pool_slots;
-    Pool W;
-    W.slots = P;
-    W.base = p.pool + ((size_t)blockIdx.x * (BLOCK / kWave) + (size_t)wave) * (size_t)P * kPoolWords;
-    // wave-private slot lists in LDS, after the geometry records: READY then FINISHED, 16-bit slot ids
-    unsigned short* lists = reinterpret_cast<unsigned short*>(ff_smem + L.geom_base + p.num_geoms * kGeomVec4) + (size_t)wave * 2 * P;
-    unsigned short* ready = lists;
-    unsigned short* finished = lists + P;
-    for (int j = lane; j < P; j += kWave) {
-        finished[j] = (unsigned short)j;
-        pool_set_u(W, j, kFlags, 0u);
-    }
-    int n_ready = 0, n_finished = P; // wave-uniform
-
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    int my_slot = -1; // slot whose query this lane is traversing
-    Ray ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
-    Segment S;
-    S.best = { kInf, -1, -1 };
-    S.pend = { kInf, -1, -1 };
-    S.meshes = 0u;
-    S.cur = kDone; S.sp = 0; S.mesh = -1; S.resume = 0;
-    S.osr = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
-    S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
-    S.scale = 1.f;
-    S.tbound = 0.f;
-    S.base = 0;
-
-    for (int guard = 0; guard < (1 << 28); ++guard) {
-        const int running = __popcll(__ballot(my_slot >= 0));
-        // ---- S step: a full batch of finished slots is waiting, or nothing else can make progress -----------------------
-        if (n_finished >= kWave || (n_finished > 0 && n_ready == 0 && running < p.pool_low)) {
-            const int n = n_finished < kWave ? n_finished : kWave;
-            n_finished -= n;
-            bool to_ready = false, to_finished = false;
-            int j = 0;
-            if (lane < n) {
-                j = finished[n_finished + lane];
-                const unsigned flags = pool_u(W, j, kFlags);
-                Path Q;
-                init_path(Q);
-                bool alive = (flags & kSlotAlive) != 0u;
-                if (alive) {
-                    Q.ray.ox = pool_f(W, j, kRayO); Q.ray.oy = pool_f(W, j, kRayO + 1); Q.ray.oz = pool_f(W, j, kRayO + 2);
-                    Q.ray.dx = pool_f(W, j, kRayD); Q.ray.dy = pool_f(W, j, kRayD + 1); Q.ray.dz = pool_f(W, j, kRayD + 2);
-                    Q.bx = pool_f(W, j, kBeta); Q.by = pool_f(W, j, kBeta + 1); Q.bz = pool_f(W, j, kBeta + 2);
-                    Q.ax = pool_f(W, j, kAcc); Q.ay = pool_f(W, j, kAcc + 1); Q.az = pool_f(W, j, kAcc + 2);
-                    Q.pdx = pool_f(W, j, kPrimD); Q.pdy = pool_f(W, j, kPrimD + 1); Q.pdz = pool_f(W, j, kPrimD + 2);
-                    Q.bitem = (int)pool_u(W, j, kBitem);
-                    Q.send = (int)pool_u(W, j, kSend);
-                    Q.gxy = pool_u(W, j, kGxy);
-                    const unsigned sb = pool_u(W, j, kSb);
-                    Q.s = (int)(sb & 0xFFFFFFu);
-                    Q.b = (int)(sb >> 24);
-                }
-                if (alive && (flags & kSlotHasQuery) != 0u) {
-                    Segment R;
-                    R.best.dist = pool_f(W, j, kBestDist); R.best.geom = (int)pool_u(W, j, kBestGeom); R.best.rec = (int)pool_u(W, j, kBestRec);
-                    R.pend.dist = pool_f(W, j, kPendDist); R.pend.geom = (int)pool_u(W, j, kPendGeom); R.pend.rec = (int)pool_u(W, j, kPendRec);
-                    Best best;
-                    finish_segment(L, p.tris, Q.ray, R, best);
-                    const bool hit = best.geom >= 0;
-                    MaterialRef M;
-                    M.global = nullptr;
-                    M.lds = L;
-                    M.g = best.geom;
-                    alive = shade_and_advance(p, best, hit, M, Q);
-                }
-                if (!alive) alive = acquire_pixel(p, lane, Q);
-                if (alive) {
-                    Segment R;
-                    if (STATS) probe_round(cnt.segment_rounds);
-                    begin_segment<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, Q.ray, R, cnt);
-                    cnt.rays += 1;
-                    pool_set_f(W, j, kRayO, Q.ray.ox); pool_set_f(W, j, kRayO + 1, Q.ray.oy); pool_set_f(W, j, kRayO + 2, Q.ray.oz);
-                    pool_set_f(W, j, kRayD, Q.ray.dx); pool_set_f(W, j, kRayD + 1, Q.ray.dy); pool_set_f(W, j, kRayD + 2, Q.ray.dz);
-                    pool_set_f(W, j, kBeta, Q.bx); pool_set_f(W, j, kBeta + 1, Q.by); pool_set_f(W, j, kBeta + 2, Q.bz);
-                    pool_set_f(W, j, kAcc, Q.ax); pool_set_f(W, j, kAcc + 1, Q.ay); pool_set_f(W, j, kAcc + 2, Q.az);
-                    pool_set_f(W, j, kPrimD, Q.pdx); pool_set_f(W, j, kPrimD + 1, Q.pdy); pool_set_f(W, j, kPrimD + 2, Q.pdz);
-                    pool_set_u(W, j, kBitem, (unsigned)Q.bitem);
-                    pool_set_u(W, j, kSend, (unsigned)Q.send);
-                    pool_set_u(W, j, kGxy, Q.gxy);
-                    pool_set_u(W, j, kSb, (unsigned)Q.s | ((unsigned)Q.b << 24));
-                    pool_set_f(W, j, kPendDist, R.pend.dist); pool_set_u(W, j, kPendGeom, (unsigned)R.pend.geom); pool_set_u(W, j, kPendRec, (unsigned)R.pend.rec);
-                    pool_set_f(W, j, kBestDist, R.best.dist); pool_set_u(W, j, kBestGeom, (unsigned)R.best.geom); pool_set_u(W, j, kBestRec, (unsigned)R.best.rec);
-                    pool_set_u(W, j, kMeshes, R.meshes);
-                    pool_set_u(W, j, kFlags, kSlotHasQuery | kSlotAlive);
-                    to_ready = R.meshes != 0u;
-                    to_finished = !to_ready;
-                } else {
-                    pool_set_u(W, j, kFlags, 0u); // queue drained: the slot retires
-                }
-            }
-            // file the slots (wave-wide prefix compaction into the LDS lists)
-            const unsigned long long m_r = __ballot(to_ready), m_f = __ballot(to_finished);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (to_ready) ready[n_ready + __popcll(m_r & below)] = (unsigned short)j;
-            if (to_finished) finished[n_finished + __popcll(m_f & below)] = (unsigned short)j;
-            n_ready += __popcll(m_r);
-            n_finished += __popcll(m_f);
-            continue;
-        }
-        if (running == 0 && n_ready == 0) break; // n_finished == 0 here: every slot has retired
-
-        // ---- T step: refill idle lanes, traverse a slice, retire completed queries ------------------------------------
-        {
-            const bool idle = my_slot < 0;
-            const unsigned long long m_idle = __ballot(idle);
-            const int n_idle = __popcll(m_idle);
-            if (n_ready > 0 && (n_idle >= p.pool_refill || running == 0)) {
-                const int k = __popcll(m_idle & ((1ull << lane) - 1ull));
-                if (idle && k < n_ready) {
-                    const int j = ready[n_ready - 1 - k];
-                    my_slot = j;
-                    ray.ox = pool_f(W, j, kRayO); ray.oy = pool_f(W, j, kRayO + 1); ray.oz = pool_f(W, j, kRayO + 2);
-                    ray.dx = pool_f(W, j, kRayD); ray.dy = pool_f(W, j, kRayD + 1); ray.dz = pool_f(W, j, kRayD + 2);
-                    S.best.dist = pool_f(W, j, kBestDist); S.best.geom = (int)pool_u(W, j, kBestGeom); S.best.rec = (int)pool_u(W, j, kBestRec);
-                    S.pend.dist = pool_f(W, j, kPendDist); S.pend.geom = (int)pool_u(W, j, kPendGeom); S.pend.rec = (int)pool_u(W, j, kPendRec);
-                    S.meshes = pool_u(W, j, kMeshes);
-                    S.cur = kDone; S.sp = 0; S.mesh = -1; S.resume = 0;
-                }
-                n_ready -= n_idle < n_ready ? n_idle : n_ready;
-            }
-        }
-        if (my_slot >= 0) {
-            traverse_budget<STATS>(L, p.tris, p.nodes, ray, S, cnt, p.setup_threshold, p.leaf_threshold);
-            if (segment_done(L, S)) {
-                const int j = my_slot;
-                pool_set_f(W, j, kBestDist, S.best.dist); pool_set_u(W, j, kBestGeom, (unsigned)S.best.geom); pool_set_u(W, j, kBestRec, (unsigned)S.best.rec);
-                pool_set_f(W, j, kPendDist, S.pend.dist); pool_set_u(W, j, kPendGeom, (unsigned)S.pend.geom); pool_set_u(W, j, kPendRec, (unsigned)S.pend.rec);
-            }
-        }
-        {
-            const bool done = my_slot >= 0 && segment_done(L, S);
-            const unsigned long long m_done = __ballot(done);
-            if (done) {
-                finished[n_finished + __popcll(m_done & ((1ull << lane) - 1ull))] = (unsigned short)my_slot;
-                my_slot = -1;
-            }
-            n_finished += __popcll(m_done);
-        }
     }
     flush_counters(p, lane, cnt, STATS);
 }
@@ -1652,7 +1674,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
         const bool hit = best.geom >= 0;
         MaterialRef M;
         M.global = hit ? &p.geoms[best.geom] : p.geoms;
-        M.lds = make_lds(0, 0, kBlockThreads, tid, 0);
+        M.geom_base = 0;
         M.g = 0;
         active = shade_and_advance(p, best, hit, M, P);
     }
@@ -1660,12 +1682,14 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
 }
 
 // Batch closest-hit query: intersectRays (kernel.cu:127-176) for caller-supplied rays, one thread per ray.
-template <int MODE>
+template <int MODE, bool BIG = false>
 __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatchParams p)
 {
     const int tid = threadIdx.x;
-    const Lds L = make_lds(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, ((p.num_geoms - 1) >> 5) << 5);
-    if (MODE == FF_TRACE_BVH) stage_scene(L, p.nodes, p.geoms, p.num_geoms, tid, kBlockThreads);
+    const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, BIG ? 0 : ((p.num_geoms - 1) >> 5) << 5, p.geoms,
+                                      p.tlas);
+    const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
+    if (MODE == FF_TRACE_BVH) stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);
     const int i = blockIdx.x * kBlockThreads + tid;
     const bool live = i < p.n;
@@ -1679,7 +1703,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
-    else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, p.nodes, wr, best, cnt);
+    else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, nodes4, wr, best, cnt);
     if (!live) return;
     FfIntersect out;
     out.m_intersectionPoint.x = 0.f; out.m_intersectionPoint.y = 0.f; out.m_intersectionPoint.z = 0.f;
@@ -1693,7 +1717,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
         const GeomRecord& G = p.geoms[best.geom];
         MaterialRef M;
         M.global = &G;
-        M.lds = L;
+        M.geom_base = L.geom_base;
         M.g = 0;
         float nx, ny, nz;
         world_normal(M, best, true, nx, ny, nz);
@@ -1733,7 +1757,7 @@ __global__ void combine_kernel(const KParams p)
             }
             v = make_float4(bx, by, bz, 0.f);
         } else {
-            v = p.blocksums[(size_t)b * p.pix_items + pitem];
+            v = p.blocksums[(size_t)pitem * p.num_blocks + b];
         }
         ax = ax + v.x;
         ay = ay + v.y;
@@ -1848,24 +1872,18 @@ __global__ void unpack_strips_kernel(const unsigned char* __restrict__ src, unsi
 
 } // namespace
 
+// (num_geoms: the records cached in LDS; 0 for scenes of more than 32 geometries, whose records stay in global memory)
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms)
 {
-    return (size_t)lds_nodes * sizeof(BvhNode) + (size_t)stack_depth * (size_t)block_threads * sizeof(unsigned) +
+    return (size_t)lds_nodes * sizeof(Bvh4Node) + (size_t)stack_depth * (size_t)block_threads * sizeof(unsigned) +
            (size_t)num_geoms * sizeof(GeomRecord);
-}
-
-size_t pool_list_bytes(int pool_slots, int block_threads) { return (size_t)(block_threads / 64) * 2 * (size_t)pool_slots * sizeof(unsigned short); }
-
-size_t pool_workspace_bytes(int pool_slots, int grid_blocks, int block_threads)
-{
-    return (size_t)grid_blocks * (size_t)(block_threads / 64) * (size_t)pool_slots * 28 * sizeof(unsigned);
 }
 
 int max_lds_nodes(int stack_depth, int block_threads, int num_geoms)
 {
     const long avail = (long)kLdsBudgetBytes - (long)stack_depth * (long)block_threads * (long)sizeof(unsigned) -
                        (long)num_geoms * (long)sizeof(GeomRecord);
-    return avail > 0 ? (int)(avail / (long)sizeof(BvhNode)) : 0;
+    return avail > 0 ? (int)(avail / (long)sizeof(Bvh4Node)) : 0;
 }
 
 hipError_t prepare_kernels()
@@ -1888,9 +1906,14 @@ hipError_t prepare_kernels()
     FF_SET_LDS((trace_bvh_kernel<false, 1024, true>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, false>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, true>))
-    FF_SET_LDS((trace_pool_kernel<false, 1024>))
-    FF_SET_LDS((trace_pool_kernel<true, 1024>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true, true>))
+    FF_SET_LDS((trace_bvh_kernel<true, 512, true, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true, true>))
+    FF_SET_LDS((trace_bvh_kernel<true, 768, true, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, true>))
+    FF_SET_LDS((trace_bvh_kernel<true, 1024, true, true>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
+    FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH, true>))
 #undef FF_SET_LDS
     return hipSuccess;
 }
@@ -1902,18 +1925,15 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
     const char* name = "";
     if (trace_mode == FF_TRACE_BVH) {
         const dim3 block(block_threads);
-        if (p.pool != nullptr) {
-            const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, 1024, p.num_geoms) + pool_list_bytes(p.pool_slots, 1024);
-            if (collect_stats) hipLaunchKernelGGL((trace_pool_kernel<true, 1024>), grid, dim3(1024), lds, stream, p);
-            else hipLaunchKernelGGL((trace_pool_kernel<false, 1024>), grid, dim3(1024), lds, stream, p);
-            if (kernel_name) *kernel_name = collect_stats ? "trace_pool_kernel<true, 1024>" : "trace_pool_kernel<false, 1024>";
-            return hipGetLastError();
-        }
-        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms);
-        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr || p.num_geoms > 32; // any extra: the full kernel
+        const bool big = p.num_geoms > kChunkGeometries;
+        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, big ? 0 : p.num_geoms);
+        const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr; // any extra: the full kernel
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
-        if (collect_stats) {                                                                                              \
+        if (big) {                                                                                                        \
+            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, true>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, true>"; } \
+        } else if (collect_stats) {                                                                                       \
             if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true>"; } \
             else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false>"; } \
         } else {                                                                                                          \
@@ -1962,10 +1982,12 @@ hipError_t launch_accumulate(float* sum, const float* frame, float* mean, unsign
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream)
 {
     if (p.n <= 0) return hipSuccess;
-    const size_t lds = trace_mode == FF_TRACE_BVH ? bvh_lds_bytes(p.lds_nodes, p.stack_depth, kBlockThreads, p.num_geoms)
+    const bool big = p.num_geoms > kChunkGeometries;
+    const size_t lds = trace_mode == FF_TRACE_BVH ? bvh_lds_bytes(p.lds_nodes, p.stack_depth, kBlockThreads, big ? 0 : p.num_geoms)
                                                   : (size_t)kBruteBatchTris * sizeof(TriRecord);
     const dim3 grid((p.n + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
-    if (trace_mode == FF_TRACE_BVH) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH>), grid, block, lds, stream, p);
+    if (trace_mode == FF_TRACE_BVH && big) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH, true>), grid, block, lds, stream, p);
+    else if (trace_mode == FF_TRACE_BVH) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BRUTE_FORCE>), grid, block, lds, stream, p);
     return hipGetLastError();
 }

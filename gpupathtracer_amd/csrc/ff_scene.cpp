@@ -306,6 +306,71 @@ int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams&
     return node_base;
 }
 
+namespace {
+
+struct TopItem {
+    int record;
+    float mn[3], mx[3], centre[3];
+};
+
+// Builds the subtree over items [first, last) and returns its link; inner nodes are appended to `nodes`.
+int build_top(std::vector<TopItem>& items, int first, int last, std::vector<BvhNode>& nodes, int depth, int* max_depth, float* out_mn, float* out_mx)
+{
+    if (last - first == 1) {
+        for (int k = 0; k < 3; ++k) { out_mn[k] = items[first].mn[k]; out_mx[k] = items[first].mx[k]; }
+        return ~items[first].record;
+    }
+    float cmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, cmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (int i = first; i < last; ++i)
+        for (int k = 0; k < 3; ++k) { cmn[k] = std::min(cmn[k], items[i].centre[k]); cmx[k] = std::max(cmx[k], items[i].centre[k]); }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+        if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+    const int mid = first + (last - first) / 2;
+    std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + last,
+                     [axis](const TopItem& a, const TopItem& b) { return a.centre[axis] < b.centre[axis] || (a.centre[axis] == b.centre[axis] && a.record < b.record); });
+    const int index = (int)nodes.size();
+    nodes.push_back(BvhNode());
+    *max_depth = std::max(*max_depth, depth + 1);
+    float lmn[3], lmx[3], rmn[3], rmx[3];
+    const int left = build_top(items, first, mid, nodes, depth + 1, max_depth, lmn, lmx);
+    const int right = build_top(items, mid, last, nodes, depth + 1, max_depth, rmn, rmx);
+    BvhNode& nd = nodes[index];
+    for (int k = 0; k < 3; ++k) {
+        nd.lmin[k] = lmn[k]; nd.lmax[k] = lmx[k];
+        nd.rmin[k] = rmn[k]; nd.rmax[k] = rmx[k];
+        out_mn[k] = std::min(lmn[k], rmn[k]);
+        out_mx[k] = std::max(lmx[k], rmx[k]);
+    }
+    nd.left = left;
+    nd.right = right;
+    nd.pad0 = nd.pad1 = 0;
+    return index;
+}
+
+} // namespace
+
+int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes)
+{
+    nodes.clear();
+    std::vector<TopItem> items(geoms.size());
+    for (size_t i = 0; i < geoms.size(); ++i) {
+        TopItem& it = items[i];
+        it.record = (int)i;
+        for (int k = 0; k < 3; ++k) {
+            it.mn[k] = geoms[i].wmin[k];
+            it.mx[k] = geoms[i].wmax[k];
+            // (a geometry nothing can hit carries an inverted box at 3e38: its centre only has to be finite)
+            it.centre[k] = 0.5f * std::min(it.mn[k], 1.0e30f) + 0.5f * std::max(std::min(it.mx[k], 1.0e30f), -1.0e30f);
+        }
+    }
+    int depth = 0;
+    float mn[3], mx[3];
+    nodes.reserve(geoms.size());
+    build_top(items, 0, (int)items.size(), nodes, 0, &depth, mn, mx);
+    return depth;
+}
+
 // World-space AABB of a geometry from its object-space bounds (pruning only): the eight corners through the model matrix,
 // padded.  An empty object box (omn > omx) gives a box no ray can enter.
 void set_world_box(GeomRecord& r, const float omn[3], const float omx[3])

@@ -20,14 +20,23 @@ struct FfState {
     ff::GeomRecord* d_geoms = nullptr;
     ff::TriRecord* d_tris = nullptr;
     ff::TriNormals* d_normals = nullptr; // vertex normals, parallel to d_tris
-    ff::BvhNode* d_nodes = nullptr;
+    ff::BvhNode* d_nodes = nullptr;   // binary trees: what the builders write and refit works on
+    ff::Bvh4Node* d_nodes4 = nullptr; // 4-wide trees derived from them (gpu_collapse_mesh): what the trace kernels traverse;
+                                      // mesh i's nodes start at its binary slot's index (slots[i].node_first)
     int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
+    int num_nodes4 = 0, max_depth4 = 0;   // 4-wide nodes in use (sum over meshes), deepest 4-wide tree
+    ff::BvhNode* d_tlas = nullptr;        // scenes of more than kChunkGeometries geometries: tree over the geometries' world boxes
+    size_t tlas_bytes = 0;
+    int tlas_depth = 0;                   // 0: no such tree (small scene)
+    int stack_entries = 1;                // traversal stack entries per lane the BVH kernels need for this scene
+    int scene_block_threads = 0, lds_cap = 0; // BVH kernel workgroup size and LDS node slots chosen for this scene (finalize_layout)
     bool has_specular = false;
     uint64_t num_tris = 0;
     bool has_scene = false;
     // scene bookkeeping for updates (ff_update_transforms / ff_update_mesh)
     struct MeshSlot {
         int node_first = 0, node_count = 0, node_capacity = 0, depth = 0;
+        int node4_count = 0, depth4 = 0; // its 4-wide tree: nodes [node_first, node_first + node4_count) of d_nodes4
         bool parents_linked = false;
     };
     int builder = FF_BUILD_HOST_SAH;       // builder for the next upload (ff_set_builder)
@@ -50,6 +59,7 @@ struct FfState {
     // fine-grained tail (KParams::tail_samples)
     float4* d_tail_samples = nullptr;
     size_t tail_samples_bytes = 0;
+    bool tail_forced = false; // FF_TAIL_GROUP given: the fine-grained tail also for one-part frames
     int tail_group_spp = 32; // FF_TAIL_GROUP (0 = off); 32 measured best: 8 ranks +3.3 %, 1 rank +0.2 % (16: +3 % / -1.1 %, 8: +3 % / -5 %)
     // progressive accumulation (ff_render_progressive)
     float* d_accum = nullptr;
@@ -65,10 +75,7 @@ struct FfState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = ff::kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
-    int scheduler = 0;      // 0 = time-sliced kernel, 1 = path-pool kernel (FF_SCHEDULER=pool)
-    int pool_slots = 192, pool_refill = 16, pool_low = 24;
-    unsigned* d_pool = nullptr;
-    size_t pool_bytes = 0;
+    bool setup_threshold_forced = false;
     int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
@@ -81,6 +88,7 @@ struct FfState {
     FfDistContext* dist = nullptr;
     // a frame enqueued by render_enqueue and not yet finished by render_finish
     int pending_launches = 0;
+    uint32_t pending_flags = 0;
     bool pending = false;
     // fault injection for tests (FF_DEBUG_FAIL_ALLOC=k: the k-th scene allocation of every upload reports out-of-memory)
     int debug_fail_alloc = -1, alloc_countdown = -1;

@@ -11,13 +11,13 @@ import numpy as np
 from . import types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfirefly_hip.so")
+LIB_PATH = os.environ.get("FF_LIB_PATH") or os.path.join(_HERE, "libfirefly_hip.so")  # FF_LIB_PATH: another build of the same library (A/B runs)
 
 # every exported symbol declared in include/firefly/ff_api.h
 EXPORTS = [
     "ff_create", "ff_destroy", "ff_last_error", "ff_version", "ff_set_stream",
     "ff_geometry_init", "ff_bxdf_init", "ff_camera_init_default", "ff_camera_update_basis", "ff_camera_ray_matrix",
-    "ff_render_tile", "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh",
+    "ff_render_tile", "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh", "ff_debug_download_bvh4",
     "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
@@ -39,6 +39,22 @@ class FireflyError(RuntimeError):
         self.message = message
 
 
+class _Tolerant:
+    """Prototype declarations against a library that may lack some symbols."""
+
+    class _Missing:
+        argtypes = restype = None
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._lib, name)
+        except AttributeError:
+            return _Tolerant._Missing()
+
+
 def load():
     """Load libfirefly_hip.so (once) and declare prototypes. Raises if the library has not been built."""
     global _lib
@@ -48,7 +64,9 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension has not been built (run __graft_entry__.build()); "
             "there is no CPU fallback for the trace path")
-    lib = C.CDLL(LIB_PATH)
+    real = C.CDLL(LIB_PATH)
+    # (an older build loaded through FF_LIB_PATH for an A/B run may lack the newest entry points: skip their prototypes)
+    lib = _Tolerant(real) if os.environ.get("FF_LIB_PATH") else real
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     P = C.POINTER
     lib.ff_create.argtypes = [P(vp), i32]
@@ -72,6 +90,7 @@ def load():
     lib.ff_update_mesh.argtypes = [vp, i32, P(T.FfTriangle), i32, i32]
     lib.ff_build_stats.argtypes = [vp, P(T.FfBuildStats)]
     lib.ff_debug_download_bvh.argtypes = [vp, vp, i32, P(i32), vp, i32, P(i32), P(i32), i32]
+    lib.ff_debug_download_bvh4.argtypes = [vp, vp, i32, P(i32), P(i32), i32]
     lib.ff_scene_info.argtypes = [P(T.FfGeometry), i32, P(T.FfSceneInfo)]
     lib.ff_render.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), vp, i32, vp, i32]
     lib.ff_render_tile.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, i32, i32, i32, vp, i32, vp, i32]
@@ -115,8 +134,8 @@ def load():
     lib.ff_multi_render.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, vp, i32, vp, i32]
     lib.ff_multi_render_to_pbo.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32]
     lib.ff_multi_stats.argtypes = [vp, P(T.FfStats)]
-    _lib = lib
-    return lib
+    _lib = real
+    return real
 
 
 def check(status):
@@ -254,6 +273,17 @@ class Tracer:
         check(self._lib.ff_debug_download_bvh(self._state, nodes.ctypes.data, nn.value, C.byref(nn), tris.ctypes.data, nt.value, C.byref(nt),
                                               table.ctypes.data_as(C.POINTER(C.c_int)), num_geometries))
         return nodes[:nn.value], tris[:nt.value], table
+
+    def download_bvh4(self, num_geometries):
+        """(4-wide nodes [capacity] with fields mn[3][4], mx[3][4], link[4]; table int32 [num_geometries, 6] = first node, node
+        count, depth, first LDS slot, nodes in LDS, LDS node slots)."""
+        cap = C.c_int(0)
+        check(self._lib.ff_debug_download_bvh4(self._state, None, 0, C.byref(cap), None, 0))
+        nodes = np.zeros(max(cap.value, 1), dtype=T.BVH4_NODE_DTYPE)
+        table = np.full((num_geometries, 6), -1, dtype=np.int32)
+        check(self._lib.ff_debug_download_bvh4(self._state, nodes.ctypes.data, cap.value, C.byref(cap),
+                                               table.ctypes.data_as(C.POINTER(C.c_int)), num_geometries))
+        return nodes[:cap.value], table
 
     def set_collect_stats(self, on):
         check(self._lib.ff_set_collect_stats(self._state, 1 if on else 0))

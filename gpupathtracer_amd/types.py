@@ -103,7 +103,7 @@ class FfStats(C.Structure):
     _fields_ = [
         ("rays_traced", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("planes_tested", C.c_uint64),
         ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-        ("kernel_launches", C.c_uint32), ("_reserved", C.c_uint32),
+        ("kernel_launches", C.c_uint32), ("flags", C.c_uint32),
         ("scene_bytes_nodes", C.c_uint64), ("scene_bytes_tris", C.c_uint64),
     ]
 
@@ -125,6 +125,10 @@ BVH_NODE_DTYPE = _np.dtype([("lmin", _np.float32, 3), ("left", _np.int32), ("lma
 TRI_RECORD_DTYPE = _np.dtype([("v0", _np.float32, 3), ("orig_index", _np.int32), ("e1", _np.float32, 3), ("cull_margin", _np.float32),
                               ("e2", _np.float32, 3), ("pad1", _np.int32)])
 assert BVH_NODE_DTYPE.itemsize == 64 and TRI_RECORD_DTYPE.itemsize == 48
+# 4-wide traversal node (csrc/ff_internal.h Bvh4Node): box planes [axis][slot] and links (>= 0: node relative to the mesh's root, < 0: leaf)
+BVH4_NODE_DTYPE = _np.dtype([("mn", _np.float32, (3, 4)), ("mx", _np.float32, (3, 4)), ("link", _np.int32, 4)])
+assert BVH4_NODE_DTYPE.itemsize == 112
+BVH4_EMPTY_LINK = 0x7fffffff
 
 
 class FfSceneInfo(C.Structure):

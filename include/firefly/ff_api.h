@@ -120,6 +120,12 @@ FF_API int ff_build_stats(FfState* state, FfBuildStats* out_stats);
 FF_API int ff_debug_download_bvh(FfState* state, void* nodes, int max_nodes, int* out_nodes, void* tris, int max_tris, int* out_tris,
                                  int* mesh_table, int max_geometries);
 
+/* The 4-wide trees the trace kernels traverse (derived on the device from the binary trees above): up to `max_nodes`
+ * 112-byte nodes of the whole array (*out_capacity = its length; mesh i's nodes start at its binary root's index and link
+ * to each other relative to it); mesh_table (optional) receives per uploaded geometry {first node, node count, depth,
+ * first LDS slot, nodes cached in LDS, LDS node slots of the scene}. */
+FF_API int ff_debug_download_bvh4(FfState* state, void* nodes4, int max_nodes, int* out_capacity, int* mesh_table, int max_geometries);
+
 /* Host-only dry run of the scene compiler: sizes, BVH shape and a structural self-check.  Needs no GPU. */
 FF_API int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneInfo* out_info);
 

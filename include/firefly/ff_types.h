@@ -166,10 +166,12 @@ typedef struct FfStats {
     double   kernel_ms;          /* sum of trace-kernel durations, HIP events on the launch stream */
     double   total_ms;           /* host wall clock of the whole call */
     uint32_t kernel_launches;    /* number of trace-kernel launches in the call */
-    uint32_t _reserved;          /* reserved */
+    uint32_t flags;              /* FF_STATS_* bits about how the frame was scheduled */
     uint64_t scene_bytes_nodes;  /* device bytes of BVH nodes */
     uint64_t scene_bytes_tris;   /* device bytes of triangle records */
 } FfStats;
+#define FF_STATS_TAIL_ITEMS 1u             /* the frame's last sample block was handed out as fine-grained items (multi-part frames) */
+#define FF_STATS_TAIL_SKIPPED_TOO_LARGE 2u /* ... was wanted, but its per-sample buffer would pass 4 GiB: rendered with whole-block items */
 
 /* Which builder produces the BVH (ff_set_builder). */
 typedef enum FfBuilder {

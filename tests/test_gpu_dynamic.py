@@ -99,6 +99,82 @@ def check_tree(nodes, tris, table, max_leaf=4):
     return walked
 
 
+def check_tree4(nodes4, tris, table, table4, max_leaf=4):
+    """The 4-wide trees the kernels traverse (derived on the device from the binary ones): per mesh, every node is reached
+    exactly once from node 0 through links relative to the mesh's first node, empty slots are inverted boxes, all triangles
+    sit in exactly one leaf, every slot box encloses what is below it, node count and depth as reported, and the LDS shares
+    of the meshes do not overlap.  Returns the number of nodes walked."""
+    walked = 0
+    v0 = tris["v0"].astype(np.float64)
+    verts = np.stack([v0, v0 + tris["e1"], v0 + tris["e2"]], axis=1)
+    tmin, tmax = verts.min(axis=1), verts.max(axis=1)
+    lds_ranges = []
+    for (root, _, tri_first, tri_count, _), (first4, count4, depth4, lds_first, lds_nodes, lds_cap) in zip(table, table4):
+        if root < 0:
+            assert first4 < 0 and count4 == 0
+            continue
+        assert first4 == root and 1 <= count4 and 0 <= lds_nodes <= count4 and lds_first + lds_nodes <= lds_cap
+        lds_ranges.append((lds_first, lds_first + lds_nodes))
+        slot = nodes4[first4:first4 + count4]
+        links = slot["link"].astype(np.int64)                     # [n, 4]
+        bmin = np.transpose(slot["mn"], (0, 2, 1)).astype(np.float64)  # [n, 4 slots, 3 axes]
+        bmax = np.transpose(slot["mx"], (0, 2, 1)).astype(np.float64)
+        empty = links == T.BVH4_EMPTY_LINK
+        inner = (links >= 0) & ~empty
+        leaf = links < 0
+        assert (~empty[:, 0]).all(), "a node without a first slot"
+        assert (np.diff(empty.astype(np.int8), axis=1) >= 0).all(), "empty slots must trail"
+        assert np.isposinf(bmin[empty]).all() and np.isneginf(bmax[empty]).all()
+        assert (links[inner] < count4).all(), "inner link outside the mesh's nodes"
+        seen = np.zeros(count4, dtype=np.int32)
+        frontier = np.array([0], dtype=np.int64)
+        levels = 0
+        while frontier.size:
+            levels += 1
+            assert levels <= 256
+            np.add.at(seen, frontier, 1)
+            nxt = links[frontier]
+            frontier = nxt[(nxt >= 0) & (nxt != T.BVH4_EMPTY_LINK)]
+        assert (seen == 1).all(), f"{(seen != 1).sum()} 4-wide nodes are not reached exactly once"
+        assert levels == depth4, (levels, depth4)
+        ref = ~links
+        lf, lc = ref >> 3, (ref & 7) + 1
+        assert (lc[leaf] <= max_leaf).all()
+        assert ((lf[leaf] >= tri_first) & (lf[leaf] + lc[leaf] <= tri_first + tri_count)).all()
+        cover = np.zeros(tri_count + 1, dtype=np.int64)
+        np.add.at(cover, lf[leaf] - tri_first, 1)
+        np.add.at(cover, lf[leaf] + lc[leaf] - tri_first, -1)
+        assert (np.cumsum(cover)[:-1] == 1).all(), "some triangles are not in exactly one leaf of the 4-wide tree"
+        sub_min = np.full((count4, 4, 3), np.inf)
+        sub_max = np.full((count4, 4, 3), -np.inf)
+        for k in range(max_leaf):
+            m = leaf & (lc > k)
+            idx = lf[m] + k
+            sub_min[m] = np.minimum(sub_min[m], tmin[idx])
+            sub_max[m] = np.maximum(sub_max[m], tmax[idx])
+        own_min, own_max = bmin.min(axis=1), bmax.max(axis=1)  # (empty slots are inverted: they do not contribute)
+        child = links[inner]
+        sub_min[inner] = own_min[child]
+        sub_max[inner] = own_max[child]
+        tol = 1e-6 * max(1.0, float(np.abs(tmin[tri_first:tri_first + tri_count]).max()), float(np.abs(tmax[tri_first:tri_first + tri_count]).max()))
+        used = ~empty
+        assert (bmin[used] <= sub_min[used] + tol).all() and (bmax[used] >= sub_max[used] - tol).all(), "a slot box does not enclose its subtree"
+        walked += count4
+    lds_ranges.sort()
+    for (a0, a1), (b0, b1) in zip(lds_ranges, lds_ranges[1:]):
+        assert a1 <= b0, "LDS shares overlap"
+    return walked
+
+
+def check_trees(t, num_geometries):
+    """Binary trees (what the builders wrote) and the 4-wide trees derived from them, as the device holds them now."""
+    nodes, tris, table = t.download_bvh(num_geometries)
+    walked = check_tree(nodes, tris, table)
+    nodes4, table4 = t.download_bvh4(num_geometries)
+    check_tree4(nodes4, tris, table, table4)
+    return walked
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_golden_frames_with_device_built_trees(lbvh_tracer, golden, name):
     scene, cam, params = build_case(name)
@@ -116,6 +192,8 @@ def test_device_built_tree_structure(lbvh_tracer, mesh):
     lbvh_tracer.upload_scene(scene)
     nodes, tris, table = lbvh_tracer.download_bvh(len(scene))
     walked = check_tree(nodes, tris, table)
+    nodes4, table4 = lbvh_tracer.download_bvh4(len(scene))
+    assert 1 <= check_tree4(nodes4, tris, table, table4) <= walked
     bs = lbvh_tracer.build_stats()
     assert walked >= 1 and bs.bvh_max_depth >= 1
     # the records are the host compiler's records (same arithmetic), only the order differs
@@ -130,7 +208,12 @@ def test_device_built_tree_structure(lbvh_tracer, mesh):
 def test_host_built_tree_structure(tracer):
     scene = scenes.cornell_wahoo_scene()
     tracer.upload_scene(scene)
-    check_tree(*tracer.download_bvh(len(scene)))
+    nodes, tris, table = tracer.download_bvh(len(scene))
+    walked = check_tree(nodes, tris, table)
+    nodes4, table4 = tracer.download_bvh4(len(scene))
+    walked4 = check_tree4(nodes4, tris, table, table4)
+    assert walked4 * 2 <= walked + 2 * len(scene)  # every second level went away
+    assert table4[:, 4].sum() == min(table4[:, 1].sum(), table4[0, 5]) or table4[:, 4].sum() <= table4[0, 5]
 
 
 def test_duplicate_centroids_and_degenerate_extent(lbvh_tracer):
@@ -141,7 +224,7 @@ def test_duplicate_centroids_and_degenerate_extent(lbvh_tracer):
     flat[20:, 0:9:3] += 2.0                    # ... and a second coincident pile shifted in x
     scene = scenes.reference_scene(flat)
     lbvh_tracer.upload_scene(scene)
-    check_tree(*lbvh_tracer.download_bvh(len(scene)))
+    check_trees(lbvh_tracer, len(scene))
 
 
 def _with_mesh(scene, geometry_index, triangles=None, position=None, rotation=None, scale=None):
@@ -192,7 +275,7 @@ def test_update_mesh_matches_fresh_upload_and_oracle(builder, mode):
         t.update_mesh(gi, moved, mode)
         bs = t.build_stats()
         assert bs.last_operation == (1 if mode == T.UPDATE_REFIT else 2)
-        check_tree(*t.download_bvh(len(scene)))
+        check_trees(t, len(scene))
         rgb8, rad = t.render(cam, params)
     with lib.Tracer(0) as fresh:
         fresh.upload_scene(scene2)
@@ -214,7 +297,7 @@ def test_refit_twice_then_rebuild(lbvh_tracer):
     for step, mode in enumerate([T.UPDATE_REFIT, T.UPDATE_REFIT, T.UPDATE_REBUILD, T.UPDATE_REFIT]):
         moved = _deform(base, phase=0.4 * (step + 1))
         lbvh_tracer.update_mesh(gi, moved, mode)
-        check_tree(*lbvh_tracer.download_bvh(len(scene)))
+        check_trees(lbvh_tracer, len(scene))
         rad = lbvh_tracer.render(cam, params)[1]
         with lib.Tracer(0) as fresh:
             fresh.upload_scene(_with_mesh(scene, gi, triangles=moved))
@@ -273,8 +356,7 @@ def test_million_triangle_device_build(lbvh_tracer):
     lbvh_tracer.upload_scene(scene)
     bs = lbvh_tracer.build_stats()
     assert bs.num_triangles == scene.triangle_count >= 983040
-    nodes, tris, table = lbvh_tracer.download_bvh(len(scene))
-    check_tree(nodes, tris, table)
+    check_trees(lbvh_tracer, len(scene))
     cam = scenes.posed_camera(160, 90, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     params = lib.render_params(160, 90, 4, 2, 11, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
     rgb8, rad = lbvh_tracer.render(cam, params)
@@ -328,11 +410,52 @@ def test_tiny_meshes_on_every_builder(count):
         with lib.Tracer(0) as t:
             t.set_builder(builder)
             t.upload_scene(scene)
-            check_tree(*t.download_bvh(len(scene)))
+            check_trees(t, len(scene))
             rgb8, rad = t.render(cam, params)
             assert np.array_equal(rgb8, o_rgb8) and same_bits(rad, o_rad), (builder, count)
             if builder != T.BUILD_HOST_SAH:
                 t.update_mesh(_mesh_index(scene), tris, T.UPDATE_REBUILD)
             t.update_mesh(_mesh_index(scene), tris, T.UPDATE_REFIT)
-            check_tree(*t.download_bvh(len(scene)))
+            check_trees(t, len(scene))
             assert same_bits(t.render(cam, params)[1], o_rad)
+
+
+@pytest.mark.parametrize("builder", [T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC, T.BUILD_HOST_SAH])
+def test_clustered_mesh_gives_a_deep_tree_that_still_renders(builder):
+    """Triangles whose spacing shrinks geometrically (every Morton split peels one off): the device builders produce their
+    deepest trees here.  The traversal stack lives in LDS (4 bytes x workgroup size per level of the 4-wide tree), so the
+    library must pick a workgroup size whose stacks fit — or say that it cannot — instead of failing the launch."""
+    rng = np.random.default_rng(3)
+    n = 1500
+    tris = np.zeros((n, 24), dtype=np.float32)
+    centre = np.stack([2.0 ** -(np.arange(n) / 25.0), 0.7 * 2.0 ** -(np.arange(n) / 31.0), 0.4 * 2.0 ** -(np.arange(n) / 19.0)], axis=1)
+    size = 0.02 * 2.0 ** -(np.arange(n) / 25.0)
+    for v in range(3):
+        tris[:, 3 * v:3 * v + 3] = (centre + rng.normal(size=(n, 3)) * size[:, None]).astype(np.float32)
+    red = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(0.8, 0.3, 0.2))
+    light = scenes.make_bxdf(T.BXDF_EMITTER, emissive=(1, 1, 1), intensity=2.0)
+    scene = scenes.Scene().add_mesh(tris, (-1.0, -0.5, 0.0), (0, 30, 0), (3, 3, 3), red) \
+        .add_plane((0, 0, -2.5), (0, 0, 0), (8, 8, 8), red).add_plane((0, 3, 0), (90, 0, 0), (8, 8, 8), light).finalize()
+    cam = scenes.posed_camera(96, 64, position=(0.0, 0.3, 4.0), yaw=-90.0, pitch=0.0)
+    with lib.Tracer(0) as t:
+        t.set_builder(builder)
+        t.upload_scene(scene)
+        check_trees(t, len(scene))
+        _, table4 = t.download_bvh4(len(scene))
+        depth4 = int(table4[:, 2].max())
+        brute = t.render(cam, lib.render_params(96, 64, 4, 2, seed=3, trace_mode=T.TRACE_BRUTE_FORCE))
+        assert brute[1].max() > 0
+        try:
+            bvh = t.render(cam, lib.render_params(96, 64, 4, 2, seed=3))
+        except lib.FireflyError as e:
+            assert e.status == T.FF_ERR_UNSUPPORTED and "traversal stack" in e.message and depth4 > 70
+        else:
+            assert np.array_equal(bvh[0], brute[0]) and same_bits(bvh[1], brute[1])
+            block = int(t.kernel_name().split(",")[1])
+            assert (depth4 + 1) * block * 4 + len(scene) * 288 <= 160 * 1024
+            rays = np.stack([np.tile([0.0, 0.3, 4.0], (200, 1)), rng.normal(size=(200, 3))], axis=0).astype(np.float32)
+            a = t.intersect_rays(rays[0], rays[1], T.TRACE_BVH)
+            b = t.intersect_rays(rays[0], rays[1], T.TRACE_BRUTE_FORCE)
+            assert np.array_equal(a["hit"], b["hit"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))
+    if builder == T.BUILD_GPU_LBVH:
+        assert depth4 >= 12  # the point of the test: this input is deep

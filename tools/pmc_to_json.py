@@ -42,7 +42,7 @@ def main(root, out_path, note=""):
     m = re.search(r"(\d+)x(\d+), (\d+) bounces, (\d+) spp, camera=(\w+), trace=(\w+)", wl)
     fetch = per.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0  # KB; gfx950 reports half of a wide read (MI355X guide, HBM section)
     write = per.get("WRITE_SIZE", 0.0) * 1024.0
-    short = kernel.split("::")[-1].split("(")[0]
+    short = re.search(r"(trace_\w+<[^>]*>)", kernel).group(1)
     doc = {
         "source": "rocprofv3 --kernel-trace --pmc <group> (one group per pass, tools/pmc_passes.sh) on bench.py, MI355X; " + note,
         "workload": {"width": int(m.group(1)), "height": int(m.group(2)), "bounces": int(m.group(3)), "spp": int(m.group(4)),
