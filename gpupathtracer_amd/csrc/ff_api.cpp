@@ -26,10 +26,7 @@ void free_scene(FfState* s)
     if (s->d_normals) (void)hipFree(s->d_normals);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_nodes4) (void)hipFree(s->d_nodes4);
-    if (s->d_tlas) (void)hipFree(s->d_tlas);
-    s->d_tlas = nullptr;
-    s->tlas_bytes = 0;
-    s->tlas_depth = 0;
+    s->top_count = s->top_depth = 0;
     if (s->d_parent) (void)hipFree(s->d_parent);
     s->d_nodes4 = nullptr;
     s->num_nodes4 = s->max_depth4 = 0;
@@ -140,18 +137,21 @@ int finalize_layout(FfState* s)
     s->max_depth4 = depth4;
     // Scenes of more than kChunkGeometries geometries: the tree over the geometries' world boxes (rebuilt here because
     // transforms and refits move those boxes; a few hundred records take microseconds).
-    s->tlas_depth = 0;
+    // It lives behind the meshes' trees in the 4-wide node array (the upload reserved num_geoms nodes there).
+    s->top_count = s->top_depth = 0;
     if (s->num_geoms > kChunkGeometries) {
-        std::vector<BvhNode> top;
-        s->tlas_depth = build_geometry_tree(s->h_geoms, top);
-        int st = ensure_bytes((void**)&s->d_tlas, &s->tlas_bytes, top.size() * sizeof(BvhNode));
-        if (st != FF_OK) return st;
-        FF_HIP(hipMemcpyAsync(s->d_tlas, top.data(), top.size() * sizeof(BvhNode), hipMemcpyHostToDevice, s->stream));
-        FF_HIP(hipStreamSynchronize(s->stream)); // (`top` goes out of scope)
+        std::vector<BvhNode> top2;
+        std::vector<Bvh4Node> top4;
+        build_geometry_tree(s->h_geoms, top2);
+        s->top_depth = collapse_geometry_tree(top2, top4);
+        s->top_count = (int)top4.size();
+        if (top4.size() > (size_t)s->num_geoms) return fail(FF_ERR_HIP, "geometry tree of %zu nodes for %d geometries", top4.size(), s->num_geoms);
+        FF_HIP(hipMemcpyAsync(s->d_nodes4 + s->node_capacity, top4.data(), top4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, s->stream));
+        FF_HIP(hipStreamSynchronize(s->stream)); // (`top4` goes out of scope)
     }
-    // one entry per visited node above the cursor (inner_step) plus a spare; below them, in big scenes, the pending entries
-    // of the walk through the geometry tree: at most one sibling per level plus the two children just pushed
-    s->stack_entries = depth4 + 1 + (s->tlas_depth > 0 ? s->tlas_depth + 2 : 0);
+    // one entry per visited node above the cursor (inner_step) plus a spare; in big scenes the pending entries of the
+    // geometry tree sit below a mesh's own
+    s->stack_entries = depth4 + 1 + (s->top_depth > 0 ? s->top_depth + 1 : 0);
     if (!s->setup_threshold_forced) {
         // Traversal time slice, in inner-node rounds (trace_bvh_kernel): long enough for most queries of the scene's biggest
         // tree to finish inside one slice.  Measured best on one MI355X: 6-8 for C2 (1 000 nodes, 4.4 visits per ray), 14-20
@@ -164,8 +164,11 @@ int finalize_layout(FfState* s)
     // (a tree too deep even for 512 threads still uploads: brute-force rendering works, BVH rendering reports it)
     const int block = s->scene_block_threads > 0 ? s->scene_block_threads : kBlockThreads;
     const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_entries, block, lds_records(s))) : 0;
-    s->lds_cap = std::min(cap, nodes4);
-    int next = 0;
+    s->lds_cap = std::min(cap, nodes4 + s->top_count);
+    // the geometry tree first (every query of a big scene starts there), the meshes share the rest
+    s->top_lds_count = std::min(s->top_count, cap);
+    const int mesh_cap = cap - s->top_lds_count;
+    int next = s->top_lds_count;
     for (size_t i = 0; i < s->h_geoms.size(); ++i) {
         GeomRecord& r = s->h_geoms[i];
         r.node4_first = 0;
@@ -174,7 +177,7 @@ int finalize_layout(FfState* s)
         if (r.type != FF_GEOM_TRIANGLEMESH || s->slots[i].node4_count == 0) continue;
         const int count = s->slots[i].node4_count;
         // everything if it fits, else a share proportional to the tree's size (the top levels of every tree)
-        const int share = nodes4 <= cap ? count : (int)((int64_t)cap * count / nodes4);
+        const int share = nodes4 <= mesh_cap ? count : (int)((int64_t)mesh_cap * count / nodes4);
         r.node4_first = s->slots[i].node_first;
         r.lds_nodes = std::min(count, share);
         std::memcpy(&r.wmin[3], &next, sizeof(int));
@@ -306,9 +309,22 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             return fail(FF_ERR_UNSUPPORTED, "4-wide BVH of depth %d does not fit the LDS traversal stack (512 threads x %d levels + %d geometry records > 160 KiB); "
                         "upload with FF_BUILD_HOST_SAH or render with FF_TRACE_BRUTE_FORCE", s->max_depth4, s->max_depth4 + 1, s->num_geoms);
     }
+    if (prm->trace_mode == FF_TRACE_BVH && block_threads > 512 && !s->block_threads_forced) {
+        // A launch that gives every lane only a handful of samples (a 1-spp frame of the viewer's loop, kernel.cu:266,342:
+        // 2 M paths over 262 144 lanes) spends most of its time running dry; half-size workgroups give each lane twice the
+        // work and drain in step (the LDS layout of the scene stays valid: smaller stacks).  From about fifty samples per lane on,
+        // four waves per SIMD win.
+        // Measured on the 1080p C2 frame (ms with 512 / 768 / 1024 threads): 1 spp 3.04 / 3.33 / 3.76, 2 spp 4.83 / 4.77 / 5.70,
+        // 4 spp 8.68 / 7.28 / 7.97, 8 spp 14.7 / 11.8 / 11.5.
+        const uint64_t samples = (uint64_t)k.pix_items * (uint64_t)spp, lanes = (uint64_t)s->num_cus * 1024ull;
+        if (samples < 12ull * lanes) block_threads = 512;
+        else if (samples < 48ull * lanes) block_threads = 768;
+    }
     k.stack_depth = s->stack_entries;
     k.lds_nodes = s->lds_cap;
-    k.tlas = s->tlas_depth > 0 ? s->d_tlas : nullptr;
+    k.top_first = (int)s->node_capacity;
+    k.top_lds_first = 0;
+    k.top_lds_count = s->top_lds_count;
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
@@ -434,7 +450,10 @@ int ff_create(FfState** out_state, int device_id)
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* bt = std::getenv("FF_BLOCK_THREADS")) {
         const int v = std::atoi(bt);
-        if (v == 512 || v == 768 || v == 1024) s->block_threads = v;
+        if (v == 512 || v == 768 || v == 1024) {
+            s->block_threads = v;
+            s->block_threads_forced = true;
+        }
     }
     if (const char* e = std::getenv("FF_DEBUG_FAIL_ALLOC")) s->debug_fail_alloc = std::atoi(e);
     if (const char* e = std::getenv("FF_TAIL_GROUP")) {
@@ -581,7 +600,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     FF_HIP(scene_alloc(s, (void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
     FF_HIP(scene_alloc(s, (void**)&s->d_normals, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriNormals)));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
-    FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (node_cap ? node_cap : 1) * sizeof(Bvh4Node)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (node_cap + cs.geoms.size() + 1) * sizeof(Bvh4Node))); // (+ the geometry tree of a big scene)
     FF_HIP(scene_alloc(s, (void**)&s->d_parent, (node_cap ? node_cap : 1) * sizeof(int)));
     s->node_capacity = node_cap;
     s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
@@ -695,7 +714,7 @@ int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, cons
     static_assert(sizeof(TriNormals) == sizeof(TriRecord), "parallel arrays of equal stride");
     if (!cs.normals.empty()) FF_HIP(hipMemcpy(s->d_normals, cs.normals.data(), cs.normals.size() * sizeof(TriNormals), hipMemcpyHostToDevice));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, node_bytes));
-    FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(Bvh4Node)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (cs.nodes.size() + cs.geoms.size() + 1) * sizeof(Bvh4Node))); // (+ the geometry tree of a big scene)
     FF_HIP(scene_alloc(s, (void**)&s->d_parent, (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(int)));
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
@@ -1058,7 +1077,9 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.tris = s->d_tris;
     p.nodes4 = s->d_nodes4;
     p.stack_depth = s->stack_entries;
-    p.tlas = s->tlas_depth > 0 ? s->d_tlas : nullptr;
+    p.top_first = (int)s->node_capacity;
+    p.top_lds_first = 0;
+    p.top_lds_count = s->top_lds_count;
     p.lds_nodes = s->lds_cap; // (the records' LDS shares were laid out for the trace kernel's workgroup; 512 threads leave more room, never less)
     e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);

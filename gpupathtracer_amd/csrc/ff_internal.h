@@ -129,6 +129,12 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
 // widest axis, one geometry per leaf.  Needs at least two records.  Returns the depth (nodes on the longest root-to-leaf path).
 int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes);
 
+// The same tree in the 4-wide form the trace kernels traverse (gpu_collapse_mesh's rule: every binary node at even depth
+// becomes a 4-wide node holding its grandchildren), level by level, links relative to node 0, a geometry as
+// ~(kGeomLeafBit | record index).  Returns the depth of the 4-wide tree.
+constexpr int32_t kGeomLeafBit = 0x40000000;
+int collapse_geometry_tree(const std::vector<BvhNode>& binary, std::vector<Bvh4Node>& out);
+
 // World-space AABB of a geometry record from object-space bounds (through the record's model matrix, padded).
 void set_world_box(GeomRecord& r, const float omn[3], const float omx[3]);
 

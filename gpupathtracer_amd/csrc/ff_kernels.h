@@ -51,8 +51,10 @@ struct KParams {
     const TriRecord* tris;
     const float4* trinormals; // vertex normals (3 float4 per triangle, parallel to tris); null unless FF_SHADE_DIFFUSE_PATH_SMOOTH
     const Bvh4Node* nodes4; // the 4-wide trees of all meshes (each mesh's nodes contiguous, level by level, links relative to its root)
-    const BvhNode* tlas;    // scenes of more than kChunkGeometries geometries: binary tree over the geometries' padded world boxes
-                            // (node 0 = root; link >= 0: node, < 0: ~(geometry record index)); null otherwise
+    // scenes of more than kChunkGeometries geometries: the 4-wide tree over the geometries' padded world boxes sits in nodes4
+    // from top_first on (leaf link = ~(0x40000000 | record index)); its first top_lds_count nodes are cached in LDS at
+    // LDS node index top_lds_first
+    int top_first, top_lds_first, top_lds_count;
     int lds_nodes;   // LDS node slots (which nodes of which mesh fill them: GeomRecord::lds_nodes / lds_first)
     int stack_depth; // entries per lane in the LDS traversal stack (depth of the deepest 4-wide tree + 1)
     // outputs (local image: local_rows x width)
@@ -83,7 +85,7 @@ struct RayBatchParams {
     const GeomRecord* geoms;
     const TriRecord* tris;
     const Bvh4Node* nodes4;
-    const BvhNode* tlas;
+    int top_first, top_lds_first, top_lds_count;
     int lds_nodes;
     int stack_depth;
 };

@@ -296,6 +296,8 @@ extern __shared__ uint4 ff_smem[];
 constexpr int kGeomVec4 = (int)(sizeof(GeomRecord) / 16); // 18 float4 per geometry record
 constexpr int kNodeVec4 = (int)(sizeof(Bvh4Node) / 16);   // 7 quarters per 4-wide node: six box planes + links
 constexpr int kDone = 0x7fffffff;                         // traversal cursor of a lane with nothing left to visit
+constexpr int kMeshDone = 0x7ffffffe;                     // big scenes: the current mesh is exhausted, the walk through the geometry tree resumes
+constexpr int kGeomLeaf = 0x40000000;                     // big scenes: ~link of a geometry-tree leaf = kGeomLeaf | geometry record index
 constexpr int kPackedEntry = 0x40000000;                  // stack entry that names a node and up to three of its slots (see inner_step)
 
 struct LdsBase {
@@ -308,8 +310,10 @@ struct LdsBase {
     int last_base;  // first record of the last chunk of 32 geometry records: ((num_geoms - 1) / 32) * 32
     // Scenes of more than 32 geometries ("big", a compile-time property of the kernel instantiation): the records stay in
     // global memory (L1/L2) and a query finds its candidates by walking a tree over the geometries' world boxes (tlas).
+    // The geometry tree is a 4-wide tree like the meshes' (same nodes, same inner step, in WORLD space); its leaves are
+    // geometries: link = ~(kGeomLeaf | record index).
     const float4* geoms_g;
-    const uint4* tlas; // BvhNode array in world space; link >= 0: node, < 0: ~(geometry record index)
+    int top_first, top_lds_first, top_lds_count; // its first node in the node array and its share of the LDS node slots
 };
 // (`big` is part of the TYPE, not a field: with a field the optimiser meets a select between an LDS and a global pointer in
 // the record accessors before it has folded the flag, and this compiler crashes on it.)
@@ -320,11 +324,14 @@ struct LdsT : LdsBase {
 
 template <bool BIG = false>
 __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
-                                              int last_base = 0, const GeomRecord* geoms = nullptr, const BvhNode* tlas = nullptr)
+                                              int last_base = 0, const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0,
+                                              int top_lds_count = 0)
 {
     LdsT<BIG> L;
     L.geoms_g = reinterpret_cast<const float4*>(geoms);
-    L.tlas = reinterpret_cast<const uint4*>(tlas);
+    L.top_first = top_first;
+    L.top_lds_first = top_lds_first;
+    L.top_lds_count = top_lds_count;
     L.num_quads = num_quads;
     L.smooth_normals = smooth_normals;
     L.last_base = last_base;
@@ -354,6 +361,13 @@ __device__ __forceinline__ void stage_scene(const LDS& L, const uint4* __restric
         for (int i = tid; i < count * kNodeVec4; i += block) {
             const int j = i / kNodeVec4, k = i - j * kNodeVec4;
             ff_smem[k * L.node_cap + base + j] = src[i];
+        }
+    }
+    if constexpr (LDS::big) {
+        const uint4* src = nodes4 + (size_t)L.top_first * kNodeVec4;
+        for (int i = tid; i < L.top_lds_count * kNodeVec4; i += block) {
+            const int j = i / kNodeVec4, k = i - j * kNodeVec4;
+            ff_smem[k * L.node_cap + L.top_lds_first + j] = src[i];
         }
     }
     if constexpr (!LDS::big) {
@@ -470,8 +484,8 @@ struct Segment {
     unsigned meshes;           // candidate meshes not started yet (bit = record index - base)
     int base;                  // first geometry record of the chunk of 32 the query is working on (0 unless the scene has > 32)
     int cur, sp, mesh;         // traversal cursor (4-wide node relative to the mesh's root >= 0, leaf < 0, kDone), stack height, record index of the current mesh
-    int tl_sp;                 // big scenes: stack entries [0, tl_sp) are pending nodes / geometries of the tree over the geometries;
-                               // the current mesh's entries sit above them (0 in scenes of up to 32 geometries)
+    int tl_sp;                 // big scenes, while a mesh is being traversed: stack entries [0, tl_sp) are the pending entries of the
+                               // geometry tree, the mesh's own entries sit above them (0 otherwise)
     int node_base;             // the current mesh's first node in the global 4-wide node array
     int lds_first, lds_count;  // its nodes [0, lds_count) sit in LDS from LDS node index lds_first on
     int pnx, pny, pnz;         // box planes (quarters of a node) the ray enters through: min planes 0/1/2 or max planes 3/4/5 by the sign of its direction
@@ -696,6 +710,9 @@ __device__ __forceinline__ void scan_chunk(const LDS& L, const GeomRecord* __res
     }
 }
 
+template <class LDS>
+__device__ __forceinline__ void enter_top(const LDS& L, const Ray& wr, Segment& S);
+
 // Start a closest-hit query: empty candidate slots, then the first chunk of geometry records.
 template <bool STATS, class LDS>
 __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
@@ -714,11 +731,10 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __
     S.resume = 0;
     S.base = 0;
     if constexpr (LDS::big) {
-        // big scenes: the query starts at the root of the tree over the geometries (advance_top walks it)
+        // big scenes: the query starts at the root of the tree over the geometries, in world space
         S.meshes = 0u;
-        stack_push(L, 0, 0);
-        S.tl_sp = 1;
-        S.sp = 1;
+        enter_top(L, wr, S);
+        S.cur = 0;
         return;
     }
     scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
@@ -752,8 +768,9 @@ __device__ __forceinline__ int select_slot(const uint4 q, int c)
 template <class LDS>
 __device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restrict__ nodes4, Segment& S)
 {
-    if (S.sp == (LDS::big ? S.tl_sp : 0)) { // nothing of the current mesh is left (below: pending entries of the top-level tree)
-        S.cur = kDone;
+    if (S.sp == (LDS::big ? S.tl_sp : 0)) {
+        // nothing of the current tree is left; under a mesh of a big scene wait the pending entries of the geometry tree
+        S.cur = LDS::big && S.mesh >= 0 ? kMeshDone : kDone;
         return;
     }
     const int e = stack_pop(L, S.sp - 1);
@@ -805,7 +822,7 @@ __device__ __forceinline__ void enter_mesh(const LDS& L, int g, const Ray& wr, S
     S.lds_count = tree.w;
     S.lds_first = __float_as_int(lds_geom4(L, g, 14).w);
     S.cur = 0;
-    S.sp = LDS::big ? S.tl_sp : 0;
+    if constexpr (!LDS::big) S.sp = 0;
 }
 
 // Idle lane with candidate meshes left: enter the next one.
@@ -817,56 +834,64 @@ __device__ __forceinline__ void start_next_mesh(const LDS& L, const Ray& wr, Seg
     enter_mesh(L, g, wr, S);
 }
 
-// Big scenes: one step of the walk through the tree over the geometries' world boxes for an idle lane (S.cur == kDone,
-// S.tl_sp > 0).  An inner node pushes the children the ray can still reach (nearer one on top); a plane or sphere is
-// screened at once; a mesh becomes the lane's current mesh.  Everything is pruned against the best / pending distance
-// the lane holds NOW (front to back, so most of a crowded scene is never looked at): kernel.cu:133's loop over all
-// geometries with the same result.
-template <bool STATS, class LDS>
-__device__ __forceinline__ void advance_top(const LDS& L, int num_planes, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+// Big scenes: the world-space half of the two-level traversal.  The lane's traversal state (ray, slab constants, box planes,
+// node range) describes EITHER the geometry tree in world space (S.mesh < 0) OR one mesh in object space; the same inner
+// step serves both.
+template <class LDS>
+__device__ __forceinline__ void enter_top(const LDS& L, const Ray& wr, Segment& S)
 {
-    --S.tl_sp;
-    S.sp = S.tl_sp;
-    const int e = stack_pop(L, S.tl_sp);
-    const WorldSlab ws = make_world_slab(wr);
-    const float limit = fminf(S.best.dist, S.pend.dist);
-    if (e >= 0) {
-        const uint4* nd = L.tlas + (size_t)e * 4;
-        const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3]; // lmin|left, lmax|right, rmin, rmax
-        const float bound = (limit * 1.001f + 1.0e-3f) * ws.inv_len * 1.00001f;
-        float a0 = __builtin_fmaf(__uint_as_float(q0.x), ws.ix, ws.ox), a1 = __builtin_fmaf(__uint_as_float(q1.x), ws.ix, ws.ox);
-        float b0 = __builtin_fmaf(__uint_as_float(q0.y), ws.iy, ws.oy), b1 = __builtin_fmaf(__uint_as_float(q1.y), ws.iy, ws.oy);
-        float c0 = __builtin_fmaf(__uint_as_float(q0.z), ws.iz, ws.oz), c1 = __builtin_fmaf(__uint_as_float(q1.z), ws.iz, ws.oz);
-        const float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-        const float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), bound));
-        a0 = __builtin_fmaf(__uint_as_float(q2.x), ws.ix, ws.ox); a1 = __builtin_fmaf(__uint_as_float(q3.x), ws.ix, ws.ox);
-        b0 = __builtin_fmaf(__uint_as_float(q2.y), ws.iy, ws.oy); b1 = __builtin_fmaf(__uint_as_float(q3.y), ws.iy, ws.oy);
-        c0 = __builtin_fmaf(__uint_as_float(q2.z), ws.iz, ws.oz); c1 = __builtin_fmaf(__uint_as_float(q3.z), ws.iz, ws.oz);
-        const float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-        const float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), bound));
-        const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
-        const int left = (int)q0.w, right = (int)q1.w;
-        const bool swap = hl && hr && rn < ln; // the nearer child goes on top
-        if (hl && hr) {
-            stack_push(L, S.tl_sp, swap ? left : right);
-            stack_push(L, S.tl_sp + 1, swap ? right : left);
-            S.tl_sp += 2;
-        } else if (hl || hr) {
-            stack_push(L, S.tl_sp, hl ? left : right);
-            S.tl_sp += 1;
-        }
-        S.sp = S.tl_sp;
-        return;
-    }
-    const int g = ~e;
-    // the candidate distances may have shrunk since the entry was pushed: test the geometry's own box once more
-    const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-    if (!slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) return;
+    S.osr = wr;
+    S.ix = safe_rcp(wr.dx);
+    S.iy = safe_rcp(wr.dy);
+    S.iz = safe_rcp(wr.dz);
+    S.ox = -wr.ox * S.ix;
+    S.oy = -wr.oy * S.iy;
+    S.oz = -wr.oz * S.iz;
+    S.pnx = S.ix < 0.0f ? 3 : 0;
+    S.pny = S.iy < 0.0f ? 4 : 1;
+    S.pnz = S.iz < 0.0f ? 5 : 2;
+    S.pfx = 3 - S.pnx;
+    S.pfy = 5 - S.pny;
+    S.pfz = 7 - S.pnz;
+    S.scale = inv_length(wr); // ray parameter per unit of world distance (ff_intersect_rays takes rays of any length)
+    refresh_tbound(S);
+    S.mesh = -1;
+    S.tl_sp = 0;
+    S.node_base = L.top_first;
+    S.lds_first = L.top_lds_first;
+    S.lds_count = L.top_lds_count;
+}
+
+// A mesh is exhausted (S.cur == kMeshDone): back to the geometry tree, whose pending entries are on the stack below.
+template <class LDS>
+__device__ __forceinline__ void leave_mesh(const LDS& L, const uint4* __restrict__ nodes4, const Ray& wr, Segment& S)
+{
+    enter_top(L, wr, S);
+    pop_subtree(L, nodes4, S);
+}
+
+// The cursor is on a leaf of the geometry tree: a plane or sphere is screened at once (kernel.cu:157-165 with the margins of
+// screen_analytic), a mesh becomes the lane's current tree (kernel.cu:138: its object-space ray).  The slot's box test in
+// the inner step has already pruned the geometry against what the lane held then.
+template <bool STATS, class LDS>
+__device__ __forceinline__ void geom_step(const LDS& L, int num_planes, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr,
+                                          Segment& S, Counters& cnt)
+{
+    const int g = (~S.cur) & (kGeomLeaf - 1);
     if (g < num_planes) {
         const float wlen = __builtin_amdgcn_rcpf(inv_length(wr));
         screen_analytic<STATS>(L, g, tris, wr, wlen, S, cnt);
+        refresh_tbound(S);
+        pop_subtree(L, nodes4, S);
     } else {
-        enter_mesh(L, g, wr, S);
+        const int floor = S.sp;
+        enter_mesh(L, g, wr, S); // (leaves the cursor alone for a mesh without a tree)
+        if (S.mesh == g) {
+            S.tl_sp = floor;
+            S.sp = floor;
+        } else {
+            pop_subtree(L, nodes4, S);
+        }
     }
 }
 
@@ -1011,7 +1036,7 @@ __device__ __forceinline__ void finish_segment(const LDS& L, const TriRecord* __
 }
 
 // Nothing left to do in the current chunk of geometry records / in the whole query.
-__device__ __forceinline__ bool chunk_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0 && S.tl_sp == 0; }
+__device__ __forceinline__ bool chunk_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
 template <class LDS>
 __device__ __forceinline__ bool segment_done(const LDS& L, const Segment& S) { return chunk_done(S) && S.base >= L.last_base; }
 
@@ -1028,11 +1053,12 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
         unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
         if (STATS) ta = __builtin_amdgcn_s_memtime();
         if constexpr (LDS::big) {
-            // idle lanes walk the tree over the geometries until each holds a mesh or has run out of candidates
+            // lanes whose mesh is exhausted resume the geometry tree; lanes on a geometry leaf screen it or enter its mesh
             for (int top = 0; top < kLoopGuard; ++top) {
-                const bool idle = S.cur == kDone && S.tl_sp > 0;
-                if (__ballot(idle) == 0ull) break;
-                if (idle) advance_top<STATS>(L, num_planes, tris, wr, S, cnt);
+                const bool back = S.cur == kMeshDone, geom = S.cur < 0 && ((~S.cur) & kGeomLeaf) != 0;
+                if (__ballot(back || geom) == 0ull) break;
+                if (back) leave_mesh(L, nodes4, wr, S);
+                else if (geom) geom_step<STATS>(L, num_planes, tris, nodes4, wr, S, cnt);
             }
         } else {
             while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
@@ -1040,16 +1066,16 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
         if (STATS) tb = __builtin_amdgcn_s_memtime();
         if (__ballot(S.cur != kDone) == 0ull) break;
         for (;;) {
-            const bool inner = S.cur >= 0 && S.cur != kDone;
+            const bool inner = (unsigned)S.cur < (unsigned)kMeshDone;
             if (__ballot(inner) == 0ull) break;
             // enough lanes hold a leaf: test the leaves now instead of idling them until the last lane finds one
-            if (__popcll(__ballot(S.cur < 0)) >= leaf_threshold) break;
+            if (__popcll(__ballot(S.cur < 0 || (LDS::big && S.cur == kMeshDone))) >= leaf_threshold) break;
             if (rounds >= limit) break;
             ++rounds;
             if (inner) inner_step<STATS>(L, nodes4, S, cnt);
         }
         if (STATS) tc = __builtin_amdgcn_s_memtime();
-        if (S.cur < 0) leaf_step<STATS>(L, tris, nodes4, wr, S, cnt);
+        if (S.cur < 0 && !(LDS::big && ((~S.cur) & kGeomLeaf) != 0)) leaf_step<STATS>(L, tris, nodes4, wr, S, cnt);
         if (STATS) {
             td = __builtin_amdgcn_s_memtime();
             if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_start += tb - ta; cnt.t_inner += tc - tb; cnt.t_leaf += td - tc; }
@@ -1562,7 +1588,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
-                                      EXTRAS && !BIG ? ((p.num_geoms - 1) >> 5) << 5 : 0, p.geoms, p.tlas);
+                                      EXTRAS && !BIG ? ((p.num_geoms - 1) >> 5) << 5 : 0, p.geoms, p.top_first, p.top_lds_first, p.top_lds_count);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, BLOCK);
 
@@ -1687,7 +1713,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
 {
     const int tid = threadIdx.x;
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, BIG ? 0 : ((p.num_geoms - 1) >> 5) << 5, p.geoms,
-                                      p.tlas);
+                                      p.top_first, p.top_lds_first, p.top_lds_count);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (MODE == FF_TRACE_BVH) stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);

@@ -371,6 +371,58 @@ int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNod
     return depth;
 }
 
+int collapse_geometry_tree(const std::vector<BvhNode>& binary, std::vector<Bvh4Node>& out)
+{
+    out.clear();
+    if (binary.empty()) return 0;
+    // breadth-first over the binary nodes that become 4-wide nodes (even depth): a node's index in `order` is its 4-wide index
+    std::vector<int> order(1, 0), index4(binary.size(), -1), level(1, 1);
+    index4[0] = 0;
+    auto grandchildren = [&](int n, int links[4], const float* mn[4], const float* mx[4]) {
+        int slots = 0;
+        const BvhNode& nd = binary[n];
+        for (int side = 0; side < 2; ++side) {
+            const int link = side == 0 ? nd.left : nd.right;
+            if (link < 0) {
+                links[slots] = link; mn[slots] = side == 0 ? nd.lmin : nd.rmin; mx[slots] = side == 0 ? nd.lmax : nd.rmax; ++slots;
+            } else {
+                const BvhNode& ch = binary[link];
+                links[slots] = ch.left; mn[slots] = ch.lmin; mx[slots] = ch.lmax; ++slots;
+                links[slots] = ch.right; mn[slots] = ch.rmin; mx[slots] = ch.rmax; ++slots;
+            }
+        }
+        return slots;
+    };
+    int depth = 1;
+    for (size_t i = 0; i < order.size(); ++i) {
+        int links[4];
+        const float *mn[4], *mx[4];
+        const int slots = grandchildren(order[i], links, mn, mx);
+        for (int q = 0; q < slots; ++q)
+            if (links[q] >= 0) {
+                index4[links[q]] = (int)order.size();
+                order.push_back(links[q]);
+                level.push_back(level[i] + 1);
+                depth = std::max(depth, level[i] + 1);
+            }
+    }
+    out.resize(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        int links[4];
+        const float *mn[4], *mx[4];
+        const int slots = grandchildren(order[i], links, mn, mx);
+        Bvh4Node& o = out[i];
+        for (int q = 0; q < 4; ++q) {
+            for (int k = 0; k < 3; ++k) {
+                o.mn[k][q] = q < slots ? mn[q][k] : std::numeric_limits<float>::infinity();
+                o.mx[k][q] = q < slots ? mx[q][k] : -std::numeric_limits<float>::infinity();
+            }
+            o.link[q] = q >= slots ? kEmptyLink : (links[q] >= 0 ? index4[links[q]] : ~(kGeomLeafBit | ~links[q]));
+        }
+    }
+    return depth;
+}
+
 // World-space AABB of a geometry from its object-space bounds (pruning only): the eight corners through the model matrix,
 // padded.  An empty object box (omn > omx) gives a box no ray can enter.
 void set_world_box(GeomRecord& r, const float omn[3], const float omx[3])

@@ -25,9 +25,9 @@ struct FfState {
                                       // mesh i's nodes start at its binary slot's index (slots[i].node_first)
     int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
     int num_nodes4 = 0, max_depth4 = 0;   // 4-wide nodes in use (sum over meshes), deepest 4-wide tree
-    ff::BvhNode* d_tlas = nullptr;        // scenes of more than kChunkGeometries geometries: tree over the geometries' world boxes
-    size_t tlas_bytes = 0;
-    int tlas_depth = 0;                   // 0: no such tree (small scene)
+    // scenes of more than kChunkGeometries geometries: the 4-wide tree over the geometries' world boxes, kept in d_nodes4
+    // from index node_capacity on (0 nodes: a small scene)
+    int top_count = 0, top_depth = 0, top_lds_count = 0;
     int stack_entries = 1;                // traversal stack entries per lane the BVH kernels need for this scene
     int scene_block_threads = 0, lds_cap = 0; // BVH kernel workgroup size and LDS node slots chosen for this scene (finalize_layout)
     bool has_specular = false;
@@ -75,7 +75,7 @@ struct FfState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = ff::kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
-    bool setup_threshold_forced = false;
+    bool setup_threshold_forced = false, block_threads_forced = false;
     int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
