@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NODE_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 24  # algorithmic bytes per BVH node visit / triangle test / ray
+NODE_BYTES, TRI_BYTES, RAY_BYTES = 112, 48, 24  # algorithmic bytes per 4-wide BVH node visit / triangle test / ray
 # VALU issue roof (same guide, "Wave scheduling" + cycle constants): 256 CUs x 4 SIMDs, one wave64 VALU instruction per
 # 2 cycles per SIMD, 2.4 GHz -> 1228.8 G wave-instructions/s
 SIMDS, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0
@@ -44,6 +44,9 @@ def parse_args():
                     help="inside: (0,0,2.4) looking down -z, every primary ray hits the box (headline); "
                          "default: the reference's literals kernel.cu:312-321 (camera 12.5 units outside, box covers ~4%% of the frame)")
     ap.add_argument("--trace-mode", choices=["bvh", "brute"], default="bvh")
+    ap.add_argument("--scene", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2: BASELINE configs[1], the headline (wahoo + cube Cornell box); c3: configs[2] (rocketman blooper scene, its own "
+                         "camera); c4: configs[3] (983 040-triangle sphere in the box) - for profiles of the other configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp-per-launch", type=int, default=0)
     ap.add_argument("--no-companion", action="store_true", help="skip the untimed default-camera frame")
@@ -73,8 +76,8 @@ def measured_pmc(args, world, kernel):
             with open(os.path.join(pdir, name)) as f:
                 d = json.load(f)
             w = d["workload"]
-            if (w["width"], w["height"], w["bounces"], w["spp"], w["n_gpus"], w["camera"], w["trace"]) == (
-                    args.width, args.height, args.bounces, args.spp, world, args.camera, args.trace_mode) and \
+            if (w["width"], w["height"], w["bounces"], w["spp"], w["n_gpus"], w["camera"], w["trace"], w.get("scene", "c2")) == (
+                    args.width, args.height, args.bounces, args.spp, world, args.camera, args.trace_mode, args.scene) and \
                     d["kernel"].replace(" ", "") == kernel.replace(" ", ""):
                 best = dict(d, file="profiles/" + name)
         except (OSError, KeyError, ValueError):
@@ -162,11 +165,15 @@ def main():
         torch.cuda.synchronize()
 
     # ---- inputs: resident before the timed region ----
-    scene = scenes.cornell_wahoo_scene()
-    if args.camera == "inside":
-        camera = scenes.posed_camera(args.width, args.height, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
-    else:
+    scene = {"c2": scenes.cornell_wahoo_scene, "c3": scenes.blooper_scene, "c4": scenes.sphere_stress_scene}[args.scene]()
+    scene_name = {"c2": "C2 wahoo.obj+cube.obj Cornell box (5184 triangles, 6 planes)", "c3": "C3 rocketman.obj+cube.obj blooper scene (6048 triangles, 2 planes)",
+                  "c4": "C4 983040-triangle sphere in the Cornell box (6 planes)"}[args.scene]
+    if args.camera == "default":
         camera = scenes.default_camera(args.width, args.height)
+    elif args.scene == "c3":
+        camera = scenes.posed_camera(args.width, args.height, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0)  # the mesh is visible past the planes
+    else:
+        camera = scenes.posed_camera(args.width, args.height, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     mode = T.TRACE_BVH if args.trace_mode == "bvh" else T.TRACE_BRUTE_FORCE
     params = lib.render_params(args.width, args.height, args.bounces, args.spp, args.seed, mode, T.SHADE_DIFFUSE_PATH,
                                T.GRID_FULL, args.spp_per_launch)
@@ -261,7 +268,7 @@ def main():
 
     # ---- companion figure (untimed region, N = 1 only): the same frame from the reference's default camera ----
     companion = None
-    if world == 1 and args.camera == "inside" and not args.no_companion:
+    if world == 1 and args.camera == "inside" and args.scene == "c2" and not args.no_companion:
         dcam = scenes.default_camera(args.width, args.height)
         step(dcam)
         torch.cuda.synchronize()
@@ -302,7 +309,7 @@ def main():
                 "hbm_frac": round(traffic / mean_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                 "algorithmic_vs_hbm": round(algo_bytes_launch / max(traffic, 1.0), 1),
                 "pmc_source": pmc["file"],
-                "note": "algorithmic bytes (SURVEY.md section 8d: 24/ray + 64/node visit + 48/triangle test + framebuffer) are served by LDS and L2; "
+                "note": "algorithmic bytes (SURVEY.md section 8d: 24/ray + 112/node visit + 48/triangle test + framebuffer) are served by LDS and L2; "
                         "`traffic` is what reaches HBM (FETCH_SIZE x2 + WRITE_SIZE from the PMC passes, scaled by rays)",
             })
         else:
@@ -310,14 +317,16 @@ def main():
                          "note": "no committed PMC measurement (profiles/*_pmc.json) matches this workload and kernel instantiation"})
         frame_ms.sort()
         out = {
-            "metric": "Mrays/s (path segments = closest-hit queries, device-counted) at 1080p, 8 bounces, 1024 spp",
+            "metric": f"Mrays/s (path segments = closest-hit queries, device-counted) at {'1080p' if (args.width, args.height) == (1920, 1080) else f'{args.width}x{args.height}'}, "
+                      f"{args.bounces} bounces, {args.spp} spp",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "frames_per_s": round(1e3 / ms_per_step, 4),
             "ms_per_frame_min": round(frame_ms[0], 3), "ms_per_frame_median": round(frame_ms[len(frame_ms) // 2], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"C2 wahoo.obj+cube.obj Cornell box (5184 triangles, 6 planes), {args.width}x{args.height}, "
+                "workload": f"{scene_name}, {args.width}x{args.height}, "
                             f"{args.bounces} bounces, {args.spp} spp, camera={args.camera}, trace={args.trace_mode}, seed {args.seed}",
+                "scene": args.scene,
                 "rays_per_frame": int(total_rays / args.steps), "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
                 "gather": gather,
             },

@@ -3,9 +3,10 @@
 // What the reference runs per pixel (kernel.cu:186-221: primary ray, brute-force closest hit over all geometries and
 // triangles, shade, 8-bit store) is restructured here as a persistent mega-kernel:
 //
-//   * one workgroup per CU; the top of the BVH node array and all geometry records are staged ONCE per workgroup into
-//     LDS (64-byte nodes with both child boxes, kept as four planes of 16-byte quarters so that a wave's reads spread over
-//     all banks) and every lane keeps its traversal stack in LDS (lane-strided: pushes / pops are bank-conflict free);
+//   * one workgroup per CU; the top of every mesh's 4-wide tree (the whole tree where it fits: the benchmark scene's does)
+//     and all geometry records are staged ONCE per workgroup into LDS (112-byte nodes: six box planes for four slots + four
+//     links, kept as seven planes of 16-byte quarters so that a wave's reads spread over all banks) and every lane keeps
+//     its traversal stack in LDS (lane-strided: pushes / pops are bank-conflict free; one entry per visited node);
 //   * lanes pull (pixel, sample block) work items from one global counter with a wave-wide ballot + prefix compaction
 //     (several short items per fetch when a frame has few samples per pixel); a lane sums its block's samples in order,
 //     terminated paths regenerate in place, and a combine pass adds a pixel's blocks in order;
@@ -1960,11 +1961,11 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
             if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, true>"; } \
             else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, true>"; } \
         } else if (collect_stats) {                                                                                       \
-            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false>"; } \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, false>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false, false>"; } \
         } else {                                                                                                          \
-            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false>"; } \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, false>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false, false>"; } \
         }                                                                                                                 \
     } while (0)
         if (block_threads == 1024) FF_LAUNCH_BVH(1024);

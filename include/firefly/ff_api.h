@@ -113,7 +113,7 @@ FF_API int ff_update_mesh(FfState* state, int geometry_index, const FfTriangle* 
 
 FF_API int ff_build_stats(FfState* state, FfBuildStats* out_stats);
 
-/* Copies the compiled scene back for inspection (tests): up to `max_nodes` 64-byte nodes and `max_tris` 48-byte triangle
+/* Copies the compiled scene back for inspection (tests): up to `max_nodes` 64-byte binary nodes and `max_tris` 48-byte triangle
  * records; the counts in use are returned through out_nodes / out_tris.  mesh_table (optional) receives, for each of the
  * first `max_geometries` uploaded geometries in the caller's order, {bvh_root, node_count, tri_first, tri_count, depth}
  * (bvh_root = -1 for planes and empty meshes).  Buffers may be null to query the counts. */

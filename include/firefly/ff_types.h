@@ -160,7 +160,7 @@ typedef struct FfRenderParams {
 /* Filled by ff_stats() after a render call. Counts are for the LAST ff_render* call on this state. */
 typedef struct FfStats {
     uint64_t rays_traced;        /* closest-hit queries executed on device (wave-reduced counter) */
-    uint64_t nodes_visited;      /* BVH inner-node visits (64 B each); only when stats collection is on */
+    uint64_t nodes_visited;      /* visits of 4-wide BVH nodes (112 B each); only when stats collection is on */
     uint64_t tris_tested;        /* ray/triangle tests (48 B each); only when stats collection is on */
     uint64_t planes_tested;      /* ray/plane tests */
     double   kernel_ms;          /* sum of trace-kernel durations, HIP events on the launch stream */
@@ -189,7 +189,7 @@ typedef enum FfMeshUpdate {
 /* Filled by ff_build_stats(): the last ff_upload_scene / ff_update_mesh / ff_update_transforms call. */
 typedef struct FfBuildStats {
     int32_t  builder;          /* FfBuilder that produced the current trees */
-    int32_t  bvh_nodes;        /* 64-byte inner nodes in use over all meshes */
+    int32_t  bvh_nodes;        /* 64-byte binary nodes in use over all meshes (the builders' trees; the kernels traverse the 4-wide trees derived from them) */
     int32_t  bvh_max_depth;    /* deepest root-to-leaf path, in inner nodes */
     int32_t  last_operation;   /* 0 upload, 1 refit, 2 rebuild, 3 transforms */
     uint64_t num_triangles;

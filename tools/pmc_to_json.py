@@ -46,7 +46,7 @@ def main(root, out_path, note=""):
     doc = {
         "source": "rocprofv3 --kernel-trace --pmc <group> (one group per pass, tools/pmc_passes.sh) on bench.py, MI355X; " + note,
         "workload": {"width": int(m.group(1)), "height": int(m.group(2)), "bounces": int(m.group(3)), "spp": int(m.group(4)),
-                     "n_gpus": bench["n_gpus"], "camera": m.group(5), "trace": m.group(6)},
+                     "n_gpus": bench["n_gpus"], "camera": m.group(5), "trace": m.group(6), "scene": bench["config"].get("scene", "c2")},
         "kernel": short,
         "rays_per_launch": int(rays),
         "kernel_ms_per_launch_profiled": bench["roofline"]["kernel_ms_per_launch"],
