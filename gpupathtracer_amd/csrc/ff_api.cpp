@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -159,6 +160,7 @@ int finalize_layout(FfState* s)
         int biggest = 1;
         for (size_t i = 0; i < s->slots.size(); ++i) biggest = std::max(biggest, s->slots[i].node4_count);
         s->setup_threshold = std::max(4, std::min(24, (int)std::lround(2.0 * std::log((double)biggest) / std::log(4.0) - 3.9)));
+        s->setup_threshold = std::min(32, s->setup_threshold + 2 * s->top_depth); // big scenes: plus the walk through the geometry tree
     }
     s->scene_block_threads = bvh_block_threads(s, s->block_threads);
     // (a tree too deep even for 512 threads still uploads: brute-force rendering works, BVH rendering reports it)
@@ -319,6 +321,14 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         const uint64_t samples = (uint64_t)k.pix_items * (uint64_t)spp, lanes = (uint64_t)s->num_cus * 1024ull;
         if (samples < 12ull * lanes) block_threads = 512;
         else if (samples < 48ull * lanes) block_threads = 768;
+    }
+    if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) {
+        unsigned long words = 0, pattern = 0;
+        if (std::sscanf(e, "%lu,%lx", &words, &pattern) == 2 && prm->trace_mode == FF_TRACE_BVH) {
+            const size_t bytes = bvh_lds_bytes(s->lds_cap, s->stack_entries, block_threads, lds_records(s));
+            k.debug_lds_words = (unsigned)std::min<size_t>(words, bytes / 4);
+            k.debug_lds_pattern = (unsigned)pattern;
+        }
     }
     k.stack_depth = s->stack_entries;
     k.lds_nodes = s->lds_cap;

@@ -125,8 +125,9 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
 
 // Binary tree over the padded world boxes of ALL geometry records (planes, spheres and meshes; records in processing order):
 // what a query of a scene with more than 32 geometries walks instead of scanning every record (kernel.cu:133's loop).
-// nodes[0] is the root; link >= 0: node index, link < 0: ~(record index).  Median splits of the box centres along the
-// widest axis, one geometry per leaf.  Needs at least two records.  Returns the depth (nodes on the longest root-to-leaf path).
+// nodes[0] is the root; link >= 0: node index, link < 0: ~(record index).  Surface-area-heuristic splits
+// (sweep over all three axes: large boxes such as a room's walls are peeled off near the root; median splits below binary
+// depth 24, so the depth stays bounded), one geometry per leaf.  Needs at least two records.  Returns the depth (nodes on the longest root-to-leaf path).
 int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes);
 
 // The same tree in the 4-wide form the trace kernels traverse (gpu_collapse_mesh's rule: every binary node at even depth

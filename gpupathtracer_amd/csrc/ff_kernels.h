@@ -73,6 +73,9 @@ struct KParams {
     unsigned tail_first_item; // queue index of the first tail item of this launch
     float4* tail_samples;    // [block_spp][pix_items] per-sample radiance of the tail block
     unsigned long long* counters; // [0] rays [1] inner-node visits [2] triangle tests [3] plane tests
+    // debugging (FF_DEBUG_LDS_FILL=words,pattern): fill that many 4-byte words of dynamic LDS with the pattern before anything is
+    // staged, to expose reads of LDS words nobody wrote
+    unsigned debug_lds_words, debug_lds_pattern;
 };
 
 struct RayBatchParams {

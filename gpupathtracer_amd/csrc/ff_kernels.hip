@@ -61,6 +61,7 @@ struct Counters {
     // phases are the counters above (nodes = inner-step lanes, tris = triangle-test lanes, planes, rays).
     unsigned inner_rounds, leaf_rounds, tri_rounds, plane_rounds, segment_rounds;
     unsigned no_mesh; // queries that needed no mesh traversal (planes only)
+    unsigned stack_overflow; // instrumented launches: pushes beyond the stack's depth (must stay 0: the depth is a bound)
     unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
     unsigned long long t_start, t_inner, t_leaf; // instrumented launches: wave cycles in mesh starts / inner phases / leaf phases
     unsigned long long t_b1, t_b2, t_b3;         // ... and in the three parts of begin_segment (quad boxes / quad screens / mesh boxes)
@@ -304,6 +305,7 @@ constexpr int kPackedEntry = 0x40000000;                  // stack entry that na
 struct LdsBase {
     int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j
     int stack_base; // uint index of this lane's stack slot 0 (in units of 4 bytes from ff_smem)
+    int stack_depth; // entries per lane
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
@@ -339,6 +341,7 @@ __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int
     L.node_cap = node_cap;
     L.stride = block;
     L.stack_base = node_cap * (kNodeVec4 * 4) + tid;
+    L.stack_depth = stack_depth;
     L.geom_base = node_cap * kNodeVec4 + (stack_depth * block) / 4;
     return L;
 }
@@ -954,6 +957,7 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
                              (k3 != 0xFFFFFFFFu ? 3u : 2u));
     const int entry = k2 == 0xFFFFFFFFu ? second_link : packed;
     if (k1 != 0xFFFFFFFFu) {
+        if (STATS && S.sp >= L.stack_depth) cnt.stack_overflow += 1;
         stack_push(L, S.sp, entry);
         ++S.sp;
     }
@@ -1066,23 +1070,35 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
         }
         if (STATS) tb = __builtin_amdgcn_s_memtime();
         if (__ballot(S.cur != kDone) == 0ull) break;
+        bool leaves_due = true;
         for (;;) {
             const bool inner = (unsigned)S.cur < (unsigned)kMeshDone;
             if (__ballot(inner) == 0ull) break;
             // enough lanes hold a leaf: test the leaves now instead of idling them until the last lane finds one
-            if (__popcll(__ballot(S.cur < 0 || (LDS::big && S.cur == kMeshDone))) >= leaf_threshold) break;
+            const bool tri_leaf = S.cur < 0 && !(LDS::big && ((~S.cur) & kGeomLeaf) != 0);
+            if (__popcll(__ballot(tri_leaf)) >= leaf_threshold) break;
             if (rounds >= limit) break;
+            if constexpr (LDS::big) {
+                // enough lanes wait on the geometry tree (a geometry leaf, an exhausted mesh): serve them first; the few lanes
+                // that hold triangles keep them for a fuller leaf phase
+                if (__popcll(__ballot(S.cur == kMeshDone || (S.cur < 0 && !tri_leaf))) >= leaf_threshold) {
+                    leaves_due = false;
+                    break;
+                }
+            }
             ++rounds;
             if (inner) inner_step<STATS>(L, nodes4, S, cnt);
         }
         if (STATS) tc = __builtin_amdgcn_s_memtime();
-        if (S.cur < 0 && !(LDS::big && ((~S.cur) & kGeomLeaf) != 0)) leaf_step<STATS>(L, tris, nodes4, wr, S, cnt);
+        if (leaves_due && S.cur < 0 && !(LDS::big && ((~S.cur) & kGeomLeaf) != 0)) leaf_step<STATS>(L, tris, nodes4, wr, S, cnt);
         if (STATS) {
             td = __builtin_amdgcn_s_memtime();
             if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_start += tb - ta; cnt.t_inner += tc - tb; cnt.t_leaf += td - tc; }
         }
-        if (__ballot(S.resume > 0) != 0ull) {
-            if (S.resume > 0) {
+        // (a lane can wait with its leaf half tested for several turns in a big scene, where an iteration may serve the geometry
+        // tree instead of the leaves: its pending candidate is resolved once, the first time round)
+        if (__ballot(S.resume > 0 && S.pend.geom >= 0) != 0ull) {
+            if (S.resume > 0 && S.pend.geom >= 0) {
                 HitPoint H;
                 resolve_pending(L, tris, wr, S.pend, S.best, H);
                 refresh_tbound(S);
@@ -1537,7 +1553,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
         const unsigned long long r0 = wave_sum((unsigned long long)cnt.inner_rounds), r1 = wave_sum((unsigned long long)cnt.leaf_rounds),
                                  r2 = wave_sum((unsigned long long)cnt.tri_rounds), r3 = wave_sum((unsigned long long)cnt.plane_rounds),
                                  r4 = wave_sum((unsigned long long)cnt.segment_rounds), r5 = wave_sum((unsigned long long)cnt.no_mesh),
-                                 r6 = wave_sum((unsigned long long)cnt.plane_exact);
+                                 r6 = wave_sum((unsigned long long)cnt.plane_exact), r7 = wave_sum((unsigned long long)cnt.stack_overflow);
         if (lane == 0) {
             if (n) atomicAdd(&p.counters[1], n);
             if (t) atomicAdd(&p.counters[2], t);
@@ -1549,6 +1565,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
             atomicAdd(&p.counters[12], r4);
             atomicAdd(&p.counters[14], r5);
             atomicAdd(&p.counters[15], r6);
+            atomicAdd(&p.counters[26], r7);
         }
         {
             const unsigned long long u0 = wave_sum(cnt.t_start), u1 = wave_sum(cnt.t_inner), u2 = wave_sum(cnt.t_leaf);
@@ -1591,9 +1608,13 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
                                       EXTRAS && !BIG ? ((p.num_geoms - 1) >> 5) << 5 : 0, p.geoms, p.top_first, p.top_lds_first, p.top_lds_count);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
+    if (p.debug_lds_words != 0u) {
+        for (unsigned i = tid; i < p.debug_lds_words; i += BLOCK) reinterpret_cast<unsigned*>(ff_smem)[i] = p.debug_lds_pattern;
+        __syncthreads();
+    }
     stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, BLOCK);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = {};
     Path P;
     init_path(P);
     Segment S;
@@ -1684,7 +1705,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     float4* batch = reinterpret_cast<float4*>(ff_smem); // triangle batch buffer
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = {};
     Path P;
     init_path(P);
     bool active = false, exhausted = false;
@@ -1728,7 +1749,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     }
     Best best;
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = {};
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, nodes4, wr, best, cnt);
     if (!live) return;

@@ -320,15 +320,44 @@ int build_top(std::vector<TopItem>& items, int first, int last, std::vector<BvhN
         for (int k = 0; k < 3; ++k) { out_mn[k] = items[first].mn[k]; out_mx[k] = items[first].mx[k]; }
         return ~items[first].record;
     }
-    float cmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, cmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    for (int i = first; i < last; ++i)
-        for (int k = 0; k < 3; ++k) { cmn[k] = std::min(cmn[k], items[i].centre[k]); cmx[k] = std::max(cmx[k], items[i].centre[k]); }
-    int axis = 0;
-    for (int k = 1; k < 3; ++k)
-        if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-    const int mid = first + (last - first) / 2;
-    std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + last,
-                     [axis](const TopItem& a, const TopItem& b) { return a.centre[axis] < b.centre[axis] || (a.centre[axis] == b.centre[axis] && a.record < b.record); });
+    // Surface-area heuristic over all three axes (sweep of the boxes sorted by centre): the walls of a room are huge flat
+    // boxes that overlap everything, and a median split would drag them through every subtree; the SAH peels them off near the
+    // root, so the small objects below get tight boxes a ray can skip.
+    const int n = last - first;
+    auto half_area = [](const float* mn, const float* mx) {
+        const double dx = std::max(0.0, (double)std::min(mx[0], 1.0e30f) - (double)std::max(mn[0], -1.0e30f));
+        const double dy = std::max(0.0, (double)std::min(mx[1], 1.0e30f) - (double)std::max(mn[1], -1.0e30f));
+        const double dz = std::max(0.0, (double)std::min(mx[2], 1.0e30f) - (double)std::max(mn[2], -1.0e30f));
+        return dx * dy + dy * dz + dz * dx;
+    };
+    int best_axis = 0, best_split = first + n / 2;
+    double best_cost = std::numeric_limits<double>::infinity();
+    std::vector<double> right_area((size_t)n);
+    for (int axis = 0; axis < 3; ++axis) {
+        std::sort(items.begin() + first, items.begin() + last,
+                  [axis](const TopItem& a, const TopItem& b) { return a.centre[axis] < b.centre[axis] || (a.centre[axis] == b.centre[axis] && a.record < b.record); });
+        float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (int i = last - 1; i > first; --i) {
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], items[i].mn[k]); mx[k] = std::max(mx[k], items[i].mx[k]); }
+            right_area[(size_t)(i - first)] = half_area(mn, mx);
+        }
+        for (int k = 0; k < 3; ++k) { mn[k] = 3.0e38f; mx[k] = -3.0e38f; }
+        for (int i = first; i < last - 1; ++i) {
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], items[i].mn[k]); mx[k] = std::max(mx[k], items[i].mx[k]); }
+            const double cost = half_area(mn, mx) * (double)(i + 1 - first) + right_area[(size_t)(i + 1 - first)] * (double)(last - i - 1);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = axis;
+                best_split = i + 1;
+            }
+        }
+    }
+    if (depth >= 24) { // (a pathological arrangement must not grow a chain: the traversal stack is sized from the depth)
+        best_split = first + n / 2;
+    }
+    const int axis = best_axis, mid = best_split;
+    std::sort(items.begin() + first, items.begin() + last,
+              [axis](const TopItem& a, const TopItem& b) { return a.centre[axis] < b.centre[axis] || (a.centre[axis] == b.centre[axis] && a.record < b.record); });
     const int index = (int)nodes.size();
     nodes.push_back(BvhNode());
     *max_depth = std::max(*max_depth, depth + 1);

@@ -14,6 +14,25 @@ if which == "c3":
     cam = scenes.posed_camera(1920, 1080, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0)
 elif which == "c4":
     scene = scenes.sphere_stress_scene(5)
+elif which.startswith("crowd"):
+    # the C2 box with N small objects scattered through the room (tools/crowd_bench.py's scene)
+    import numpy as np
+    rng = np.random.default_rng(1)
+    cube = scenes.load_mesh("cube")
+    s = scenes.Scene()
+    s.add_mesh(scenes.load_mesh("wahoo"), (0, -2.4, 0), (0, 0, 0), (0.28, 0.28, 0.28), scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0)))
+    s.add_mesh(cube, (1.5, -2.0, 1.0), (0, 0, 0), (1, 1, 1), scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(0.75, 0.75, 0.75)))
+    for _ in range(int(which[5:])):
+        k = int(rng.integers(0, 3))
+        pos, rot = tuple(rng.uniform(-2.2, 2.2, 3)), tuple(rng.uniform(-180, 180, 3))
+        bx = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=tuple(float(v) for v in rng.uniform(0.3, 0.9, 3)))
+        if k == 0:
+            s.add_mesh(cube, pos, rot, tuple(float(v) for v in rng.uniform(0.1, 0.3, 3)), bx)
+        elif k == 1:
+            s.add_sphere(float(rng.uniform(0.08, 0.2)), pos, rot, (1, 1, 1), bx)
+        else:
+            s.add_plane(pos, rot, tuple(float(v) for v in rng.uniform(0.15, 0.5, 3)), bx)
+    scene = scenes._box(s).finalize()
 else:
     scene = scenes.cornell_wahoo_scene()
 with lib.Tracer(0) as t:
