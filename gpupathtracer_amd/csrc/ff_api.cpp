@@ -107,8 +107,8 @@ int check_render_call(const FfState* s, const FfCamera* camera, const FfRenderPa
 
 namespace {
 
-// Geometry records the BVH kernels keep in LDS: all of them up to kChunkGeometries, none beyond (read from global memory).
-int lds_records(const FfState* s) { return s->num_geoms > kChunkGeometries ? 0 : s->num_geoms; }
+// Geometry records the BVH kernels keep in LDS: all of them up to kMaxLdsRecords, none beyond (read from global memory).
+int lds_records(const FfState* s) { return s->num_geoms > kMaxLdsRecords ? 0 : s->num_geoms; }
 
 // Workgroup size of the BVH kernel for the uploaded scene: the preferred size if the lane-strided traversal stacks
 // (4 bytes x workgroup size per tree level) and the geometry records fit the 160 KiB of LDS, else the largest smaller
@@ -170,6 +170,24 @@ int finalize_layout(FfState* s)
     // the geometry tree first (every query of a big scene starts there), the meshes share the rest
     s->top_lds_count = std::min(s->top_count, cap);
     const int mesh_cap = cap - s->top_lds_count;
+    // Every mesh first gets the top of its tree up to kSmallTree nodes (a crowd of small objects: their whole trees; a query
+    // that enters one must not pay a global fetch for a three-node tree), then the big trees share what is left in proportion
+    // to their sizes.
+    constexpr int kSmallTree = 8;
+    std::vector<int> share(s->h_geoms.size(), 0);
+    int left = mesh_cap, wanting = 0;
+    for (size_t i = 0; i < s->h_geoms.size(); ++i) {
+        if (s->h_geoms[i].type != FF_GEOM_TRIANGLEMESH || s->slots[i].node4_count == 0) continue;
+        share[i] = std::min(std::min(s->slots[i].node4_count, kSmallTree), left);
+        left -= share[i];
+        wanting += s->slots[i].node4_count - share[i];
+    }
+    const int pool = left;
+    for (size_t i = 0; i < s->h_geoms.size() && wanting > 0; ++i) {
+        if (s->h_geoms[i].type != FF_GEOM_TRIANGLEMESH || s->slots[i].node4_count == 0) continue;
+        const int want = s->slots[i].node4_count - share[i];
+        share[i] += wanting <= pool ? want : (int)((int64_t)pool * want / wanting);
+    }
     int next = s->top_lds_count;
     for (size_t i = 0; i < s->h_geoms.size(); ++i) {
         GeomRecord& r = s->h_geoms[i];
@@ -177,11 +195,8 @@ int finalize_layout(FfState* s)
         r.lds_nodes = 0;
         r.wmin[3] = 0.0f;
         if (r.type != FF_GEOM_TRIANGLEMESH || s->slots[i].node4_count == 0) continue;
-        const int count = s->slots[i].node4_count;
-        // everything if it fits, else a share proportional to the tree's size (the top levels of every tree)
-        const int share = nodes4 <= mesh_cap ? count : (int)((int64_t)mesh_cap * count / nodes4);
         r.node4_first = s->slots[i].node_first;
-        r.lds_nodes = std::min(count, share);
+        r.lds_nodes = std::min(s->slots[i].node4_count, share[i]);
         std::memcpy(&r.wmin[3], &next, sizeof(int));
         next += r.lds_nodes;
     }

@@ -10,6 +10,7 @@ namespace ff {
 constexpr int kBlockThreads = 512;        // default workgroup: 8 waves, one workgroup per CU shares one LDS copy of the BVH top
 constexpr int kBlockThreadsMax = 1024;    // alternative: 16 waves per workgroup (4 per SIMD), smaller node cache next to the stacks
 constexpr int kLdsBudgetBytes = 160 * 1024;
+constexpr int kMaxLdsRecords = 128;       // geometry records (288 B each) stay in LDS up to this many: 36 KB of the 160
 constexpr int kChunkGeometries = 32;      // BVH mode, up to this many geometries (the reference has 5): records resident in LDS (288 B each), one
                                           // candidate bit per record; beyond it a query walks a tree over the geometries' world boxes (KParams::tlas)
                                           // and reads the records from global memory

@@ -320,12 +320,15 @@ struct LdsBase {
 };
 // (`big` is part of the TYPE, not a field: with a field the optimiser meets a select between an LDS and a global pointer in
 // the record accessors before it has folded the flag, and this compiler crashes on it.)
-template <bool BIG>
+// BIG: 0 = up to 32 geometries (records in LDS, every query screens them all); 1 = more, records still in LDS (up to
+// kMaxLdsRecords); 2 = more than that, records read from global memory.
+template <int BIG>
 struct LdsT : LdsBase {
-    static constexpr bool big = BIG;
+    static constexpr bool big = BIG != 0;
+    static constexpr bool records_lds = BIG != 2;
 };
 
-template <bool BIG = false>
+template <int BIG = 0>
 __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
                                               int last_base = 0, const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0,
                                               int top_lds_count = 0)
@@ -374,7 +377,7 @@ __device__ __forceinline__ void stage_scene(const LDS& L, const uint4* __restric
             ff_smem[k * L.node_cap + L.top_lds_first + j] = src[i];
         }
     }
-    if constexpr (!LDS::big) {
+    if constexpr (LDS::records_lds) {
         const uint4* gsrc = reinterpret_cast<const uint4*>(geoms);
         for (int i = tid; i < num_geoms * kGeomVec4; i += block) ff_smem[L.geom_base + i] = gsrc[i];
     }
@@ -385,13 +388,13 @@ __device__ __forceinline__ void stage_scene(const LDS& L, const uint4* __restric
 template <class LDS>
 __device__ __forceinline__ float4 lds_geom4(const LDS& L, int g, int k)
 {
-    if constexpr (LDS::big) return L.geoms_g[(size_t)g * kGeomVec4 + k];
+    if constexpr (!LDS::records_lds) return L.geoms_g[(size_t)g * kGeomVec4 + k];
     return reinterpret_cast<const float4*>(ff_smem)[L.geom_base + g * kGeomVec4 + k];
 }
 template <class LDS>
 __device__ __forceinline__ int4 lds_geom_i4(const LDS& L, int g, int k)
 {
-    if constexpr (LDS::big) return reinterpret_cast<const int4*>(L.geoms_g)[(size_t)g * kGeomVec4 + k];
+    if constexpr (!LDS::records_lds) return reinterpret_cast<const int4*>(L.geoms_g)[(size_t)g * kGeomVec4 + k];
     return reinterpret_cast<const int4*>(ff_smem)[L.geom_base + g * kGeomVec4 + k];
 }
 template <class LDS>
@@ -1600,7 +1603,7 @@ __device__ __forceinline__ void init_path(Path& P)
 // shader drop out (together they cost the reference-like scenes 3.5 % otherwise, measured on one box).
 // BIG = true (with EXTRAS) is the instantiation for scenes of more than 32 geometries: records read from global memory,
 // candidates found by walking the tree over the geometries (advance_top) instead of scanning all records.
-template <bool STATS, int BLOCK, bool EXTRAS, bool BIG = false>
+template <bool STATS, int BLOCK, bool EXTRAS, int BIG = 0>
 __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
@@ -1655,7 +1658,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
         if (setup && inflight) {
             MaterialRef M;
-            M.global = BIG ? p.geoms + (hit ? best.geom : 0) : nullptr;
+            M.global = BIG == 2 ? p.geoms + (hit ? best.geom : 0) : nullptr;
             M.geom_base = L.geom_base;
             M.g = best.geom;
             active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
@@ -1730,7 +1733,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
 }
 
 // Batch closest-hit query: intersectRays (kernel.cu:127-176) for caller-supplied rays, one thread per ray.
-template <int MODE, bool BIG = false>
+template <int MODE, int BIG = 0>
 __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatchParams p)
 {
     const int tid = threadIdx.x;
@@ -1954,14 +1957,21 @@ hipError_t prepare_kernels()
     FF_SET_LDS((trace_bvh_kernel<false, 1024, true>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, false>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, true>))
-    FF_SET_LDS((trace_bvh_kernel<false, 512, true, true>))
-    FF_SET_LDS((trace_bvh_kernel<true, 512, true, true>))
-    FF_SET_LDS((trace_bvh_kernel<false, 768, true, true>))
-    FF_SET_LDS((trace_bvh_kernel<true, 768, true, true>))
-    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, true>))
-    FF_SET_LDS((trace_bvh_kernel<true, 1024, true, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true, 1>))
+    FF_SET_LDS((trace_bvh_kernel<true, 512, true, 1>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true, 1>))
+    FF_SET_LDS((trace_bvh_kernel<true, 768, true, 1>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 1>))
+    FF_SET_LDS((trace_bvh_kernel<true, 1024, true, 1>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true, 2>))
+    FF_SET_LDS((trace_bvh_kernel<true, 512, true, 2>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true, 2>))
+    FF_SET_LDS((trace_bvh_kernel<true, 768, true, 2>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 2>))
+    FF_SET_LDS((trace_bvh_kernel<true, 1024, true, 2>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
-    FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH, true>))
+    FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH, 1>))
+    FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH, 2>))
 #undef FF_SET_LDS
     return hipSuccess;
 }
@@ -1973,20 +1983,23 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
     const char* name = "";
     if (trace_mode == FF_TRACE_BVH) {
         const dim3 block(block_threads);
-        const bool big = p.num_geoms > kChunkGeometries;
-        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, big ? 0 : p.num_geoms);
+        const int big = p.num_geoms <= kChunkGeometries ? 0 : (p.num_geoms <= kMaxLdsRecords ? 1 : 2);
+        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, big == 2 ? 0 : p.num_geoms);
         const bool spheres = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr; // any extra: the full kernel
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
-        if (big) {                                                                                                        \
-            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, true>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, true>"; } \
+        if (big == 1) {                                                                                                   \
+            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, 1>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 1>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 1>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 1>"; } \
+        } else if (big == 2) {                                                                                            \
+            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, 2>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 2>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 2>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 2>"; } \
         } else if (collect_stats) {                                                                                       \
-            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, false>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false, false>"; } \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 0>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false, 0>"; } \
         } else {                                                                                                          \
-            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, false>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false, false>"; } \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 0>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false, 0>"; } \
         }                                                                                                                 \
     } while (0)
         if (block_threads == 1024) FF_LAUNCH_BVH(1024);
@@ -2030,11 +2043,12 @@ hipError_t launch_accumulate(float* sum, const float* frame, float* mean, unsign
 hipError_t launch_ray_batch(const RayBatchParams& p, int trace_mode, hipStream_t stream)
 {
     if (p.n <= 0) return hipSuccess;
-    const bool big = p.num_geoms > kChunkGeometries;
-    const size_t lds = trace_mode == FF_TRACE_BVH ? bvh_lds_bytes(p.lds_nodes, p.stack_depth, kBlockThreads, big ? 0 : p.num_geoms)
+    const int big = p.num_geoms <= kChunkGeometries ? 0 : (p.num_geoms <= kMaxLdsRecords ? 1 : 2);
+    const size_t lds = trace_mode == FF_TRACE_BVH ? bvh_lds_bytes(p.lds_nodes, p.stack_depth, kBlockThreads, big == 2 ? 0 : p.num_geoms)
                                                   : (size_t)kBruteBatchTris * sizeof(TriRecord);
     const dim3 grid((p.n + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
-    if (trace_mode == FF_TRACE_BVH && big) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH, true>), grid, block, lds, stream, p);
+    if (trace_mode == FF_TRACE_BVH && big == 1) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH, 1>), grid, block, lds, stream, p);
+    else if (trace_mode == FF_TRACE_BVH && big == 2) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH, 2>), grid, block, lds, stream, p);
     else if (trace_mode == FF_TRACE_BVH) hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BVH>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((ray_batch_kernel<FF_TRACE_BRUTE_FORCE>), grid, block, lds, stream, p);
     return hipGetLastError();

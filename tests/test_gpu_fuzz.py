@@ -46,7 +46,14 @@ def test_five_hundred_geometries_equal_brute_force_and_oracle(tracer):
             assert out[T.TRACE_BVH][1] == out[T.TRACE_BRUTE_FORCE][1]
             assert np.array_equal(out[T.TRACE_BVH][0][0], out[T.TRACE_BRUTE_FORCE][0][0])
             assert np.array_equal(out[T.TRACE_BVH][0][1].view(np.uint32), out[T.TRACE_BRUTE_FORCE][0][1].view(np.uint32))
-            assert "true, true>" in t.kernel_name() or "trace_brute" in t.kernel_name()
+    # (after the brute-force frame the name is the brute-force kernel's: ask right after a BVH frame)
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        t.render(cam, lib.render_params(32, 24, 1, 1))
+        assert t.kernel_name().endswith(", true, 2>")  # records in global memory, two-level traversal
+        t.upload_scene(fz.rand_scene(np.random.default_rng(3), small=True, crowd=80))
+        t.render(cam, lib.render_params(32, 24, 1, 1))
+        assert t.kernel_name().endswith(", true, 1>")  # records still in LDS
     small = scenes.posed_camera(28, 20, position=(0.5, 0.2, 4.5), yaw=-95.0, pitch=-4.0)
     p = lib.render_params(28, 20, 4, 2, 3, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
     tracer.upload_scene(scene)
