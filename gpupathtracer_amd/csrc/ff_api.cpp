@@ -301,15 +301,6 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.key = (unsigned)prm->seed ^ (unsigned)(prm->seed >> 32);
     k.shade_mode = prm->shade_mode;
     k.setup_threshold = s->setup_threshold;
-    {
-        // Short items (few samples per pixel and launch) are fetched several at a time: runs of about 16 samples measured
-        // best (1080p C2, Mrays/s with 1 / best items per fetch: 2 spp 3301 / 4433, 4 spp 3895 / 5950, 8 spp 5345 / 7472,
-        // 16 spp 8244 / 8626; from 32 spp on single items win because the tail of the queue is what matters then)
-        // (FF_ITEMS_PER_FETCH overrides).
-        const int samples_per_item = std::max(1, std::min(k.block_spp, k.spp_total));
-        k.items_per_fetch = std::max(1, std::min(6, 16 / samples_per_item));
-        if (const char* e = std::getenv("FF_ITEMS_PER_FETCH")) k.items_per_fetch = std::max(1, std::min(64, std::atoi(e)));
-    }
     k.leaf_threshold = s->leaf_threshold;
     k.num_geoms = s->num_geoms;
     k.num_planes = s->num_planes;
@@ -325,17 +316,6 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         if (block_threads == 0)
             return fail(FF_ERR_UNSUPPORTED, "4-wide BVH of depth %d does not fit the LDS traversal stack (512 threads x %d levels + %d geometry records > 160 KiB); "
                         "upload with FF_BUILD_HOST_SAH or render with FF_TRACE_BRUTE_FORCE", s->max_depth4, s->max_depth4 + 1, s->num_geoms);
-    }
-    if (prm->trace_mode == FF_TRACE_BVH && block_threads > 512 && !s->block_threads_forced) {
-        // A launch that gives every lane only a handful of samples (a 1-spp frame of the viewer's loop, kernel.cu:266,342:
-        // 2 M paths over 262 144 lanes) spends most of its time running dry; half-size workgroups give each lane twice the
-        // work and drain in step (the LDS layout of the scene stays valid: smaller stacks).  From about fifty samples per lane on,
-        // four waves per SIMD win.
-        // Measured on the 1080p C2 frame (ms with 512 / 768 / 1024 threads): 1 spp 3.04 / 3.33 / 3.76, 2 spp 4.83 / 4.77 / 5.70,
-        // 4 spp 8.68 / 7.28 / 7.97, 8 spp 14.7 / 11.8 / 11.5.
-        const uint64_t samples = (uint64_t)k.pix_items * (uint64_t)spp, lanes = (uint64_t)s->num_cus * 1024ull;
-        if (samples < 12ull * lanes) block_threads = 512;
-        else if (samples < 48ull * lanes) block_threads = 768;
     }
     if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) {
         unsigned long words = 0, pattern = 0;
@@ -354,6 +334,15 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
     k.counters = s->d_counters;
+    k.timeline = nullptr;
+    k.timeline_ticks = 1;
+    if (s->collect_stats && s->timeline_bucket_us > 0) {
+        const size_t rows = (size_t)s->num_cus * 2 * (kBlockThreads / 64); // one row per wave of the largest grid
+        if (!s->d_timeline) FF_HIP(hipMalloc((void**)&s->d_timeline, rows * kTimelineBuckets * sizeof(unsigned)));
+        FF_HIP(hipMemsetAsync(s->d_timeline, 0, rows * kTimelineBuckets * sizeof(unsigned), s->stream));
+        k.timeline = s->d_timeline;
+        k.timeline_ticks = (unsigned)s->timeline_bucket_us * 100u; // the wall clock ticks at 100 MHz
+    }
 
     const int blocks_per_cu = prm->trace_mode == FF_TRACE_BVH ? 1 : 2;
     int grid = s->num_cus * blocks_per_cu;
@@ -361,6 +350,24 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
 
+    {
+        // Work queue (csrc/ff_kernels.hip acquire_pixel): 16 counters in different memory channels, and a wave takes at least
+        // queue_chunk consecutive items per atomic.  One counter asked for every item serves about 10^8 requests a second, which
+        // held every frame of short items far below the saturated rate (1080p C2, before -> after: the reference's own 1-ray frame
+        // 0.40 -> 0.19 ms, path-traced 1 spp 2.98 -> 1.33 ms, 4 spp 7.3 -> 4.8, 16 spp 20.8 -> 18.0; the 1 024-spp frame from the
+        // reference's default camera, whose 64-sample items are mostly one-ray paths, 164 -> 84 ms).  With 16 counters the chunk
+        // hardly matters between 8 and 64 items (profiles/r02_q_queue_sweep.txt); it is sized to 64 samples of work, and launches that give
+        // every lane many items take 16 (1 024 spp: 969 / 965 / 958 ms with 1 / 4 / 16); what a wave holds back at the end of
+        // a launch is its tail (64 spp: 69.5 / 70.1 / 70.8 ms with 1 / 4 / 16; 128 and more cost 5-30 % everywhere).
+        const int samples_per_item = std::max(1, std::min(k.block_spp, k.spp_total));
+        const uint64_t items = (uint64_t)k.pix_items * (uint64_t)std::min(num_blocks, blocks_per_launch);
+        const uint64_t items_per_lane = items / ((uint64_t)grid * (uint64_t)block_threads);
+        const int by_item = std::min(32, std::max(4, 64 / samples_per_item)), by_launch = (int)std::min<uint64_t>(16, items_per_lane / 8);
+        k.queue_chunk = (unsigned)std::max(by_item, by_launch);
+        if (const char* e = std::getenv("FF_QUEUE_CHUNK")) k.queue_chunk = (unsigned)std::max(1, std::min(4096, std::atoi(e)));
+        k.queue_counters = std::min(kQueueCountersDefault, grid);
+        if (const char* e = std::getenv("FF_QUEUE_COUNTERS")) k.queue_counters = std::max(1, std::min(std::min(kQueueCounters, grid), std::atoi(e)));
+    }
     hipStream_t st = s->stream;
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced pixels read 0.  With the full grid the combine pass writes every pixel
     // of the window (a missed pixel gets its zero sum), so the clears are only needed for the reference's floor grid.
@@ -368,7 +375,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         if (rgb8_dev) FF_HIP(hipMemsetAsync(rgb8_dev, 0, local_pixels * 3, st));
         if (radiance_dev) FF_HIP(hipMemsetAsync(radiance_dev, 0, local_pixels * 3 * sizeof(float), st));
     }
-    FF_HIP(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), st)); // counters and the work queue behind them
+    FF_HIP(hipMemsetAsync(s->d_counters, 0, (size_t)(1 + k.queue_counters) * kQueueStride * sizeof(unsigned), st)); // counters and the work queue behind them
     FF_HIP(hipEventRecord(s->ev_begin, st));
     // Fine-grained tail: in the launch that finishes the frame, the last block (if the launch has at least four) is traced
     // as 16-sample items with per-sample storage (see KParams::tail_samples).
@@ -408,12 +415,17 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             k.tail_first_item = k.pix_items * k.whole_blocks;
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
-        if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned), st));
+        if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
         FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st, &s->last_kernel_name));
     }
     FF_HIP(launch_combine(k, st));
     FF_HIP(hipEventRecord(s->ev_end, st));
     FF_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, 28 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (k.timeline) {
+        const size_t rows = (size_t)s->num_cus * 2 * (kBlockThreads / 64);
+        s->h_timeline_rows.resize(rows * kTimelineBuckets);
+        FF_HIP(hipMemcpyAsync(s->h_timeline_rows.data(), s->d_timeline, rows * kTimelineBuckets * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    }
     s->pending = true;
     s->pending_launches = launches;
     return FF_OK;
@@ -477,10 +489,10 @@ int ff_create(FfState** out_state, int device_id)
         const int v = std::atoi(bt);
         if (v == 512 || v == 768 || v == 1024) {
             s->block_threads = v;
-            s->block_threads_forced = true;
         }
     }
     if (const char* e = std::getenv("FF_DEBUG_FAIL_ALLOC")) s->debug_fail_alloc = std::atoi(e);
+    if (const char* e = std::getenv("FF_DEBUG_TIMELINE_US")) s->timeline_bucket_us = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("FF_TAIL_GROUP")) {
         s->tail_group_spp = std::max(0, std::min(64, std::atoi(e)));
         s->tail_forced = true;
@@ -495,13 +507,13 @@ int ff_create(FfState** out_state, int device_id)
         delete s;
         return fail(FF_ERR_HIP, "ff_create: kernel preparation failed: %s (is this a gfx950 device?)", hipGetErrorString(pe));
     }
-    if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&s->d_counters, (size_t)(1 + kQueueCounters) * kQueueStride * sizeof(unsigned)) != hipSuccess || // counters, then the work-queue counters 4 KiB apart
         hipHostMalloc((void**)&s->h_counters, 32 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         ff_destroy(s);
         return fail(FF_ERR_HIP, "ff_create: allocating work buffers failed");
     }
-    s->d_queue = reinterpret_cast<unsigned*>(s->d_counters + 28);
+    s->d_queue = reinterpret_cast<unsigned*>(s->d_counters) + kQueueStride;
     *out_state = s;
     return FF_OK;
 }
@@ -523,6 +535,7 @@ int ff_destroy(FfState* s)
     if (s->d_rgb8) (void)hipFree(s->d_rgb8);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_timeline) (void)hipFree(s->d_timeline);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_end) (void)hipEventDestroy(s->ev_end);
@@ -1277,6 +1290,17 @@ int ff_set_collect_stats(FfState* s, int on)
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_set_collect_stats: state is null");
     s->collect_stats = on != 0;
+    return FF_OK;
+}
+
+int ff_debug_timeline(FfState* s, unsigned* out1024, int* bucket_us)
+{
+    clear_error();
+    if (!s || !out1024 || !bucket_us) return fail(FF_ERR_INVALID_ARG, "ff_debug_timeline: null argument");
+    std::memset(s->h_timeline, 0, sizeof s->h_timeline);
+    for (size_t i = 0; i < s->h_timeline_rows.size(); ++i) s->h_timeline[i % kTimelineBuckets] += s->h_timeline_rows[i];
+    std::memcpy(out1024, s->h_timeline, sizeof s->h_timeline);
+    *bucket_us = s->timeline_bucket_us;
     return FF_OK;
 }
 

@@ -31,7 +31,7 @@ struct KParams {
                              // whole-width strips: x0 = y0 = 0, local_width = width
     unsigned whole_blocks; // sample blocks this launch hands out as whole (pixel, block) items: block_end - block_begin, minus the tail block
     unsigned total_items; // work items of this launch: pix_items x whole_blocks (+ the tail block's group items)
-    int items_per_fetch;  // items a lane takes per queue fetch (1 for long items; more when an item is only a few samples)
+    unsigned queue_chunk; // items a wave takes from the work queue per atomic, at least (a few hundred samples of work)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
     // integrator
@@ -62,7 +62,8 @@ struct KParams {
     float4* blocksums;       // [pix_items][num_blocks] radiance sums of the sample blocks (tile-major pixel order)
     unsigned char* rgb8;     // 3 bytes per local pixel, or null
     float* radiance;         // 3 floats per local pixel, or null
-    unsigned* queue;         // work-item counter (zeroed before each launch)
+    unsigned* queue;         // work-item counters (zeroed before each launch): counter c sits kQueueStride words behind counter c - 1
+    int queue_counters;      // how many of them the launch uses (workgroup b draws from counter b % queue_counters)
     // Fine-grained tail (tail_block < 0: off).  The frame's last sample block is handed out as (pixel, group of
     // tail_group_spp samples) items that store every sample's radiance separately; the combine pass adds that block's
     // samples in order, which is bit for bit what a lane summing the block in registers computes.  The launch then runs
@@ -77,7 +78,18 @@ struct KParams {
     // debugging (FF_DEBUG_LDS_FILL=words,pattern): fill that many 4-byte words of dynamic LDS with the pattern before anything is
     // staged, to expose reads of LDS words nobody wrote
     unsigned debug_lds_words, debug_lds_pattern;
+    // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
+    // wall clock (100 MHz ticks since the first wave started; counters[27] holds that epoch), kTimelineBuckets buckets
+    unsigned* timeline;
+    unsigned timeline_ticks;
 };
+constexpr int kTimelineBuckets = 1024;
+// Work queue: up to kQueueCounters counters, 4 KiB apart so that they sit in different memory channels (atomics on one address
+// are served one after the other, about 10^8 a second for the whole GPU).
+constexpr int kQueueCounters = 64;     // buffer size; a launch uses kQueueCountersDefault of them unless FF_QUEUE_COUNTERS says otherwise
+constexpr int kQueueCountersDefault = 16;
+constexpr int kQueueStride = 1024; // in 4-byte words
+constexpr int kQueueStripe = 64;   // items: counter c owns the stripes c, c + n, c + 2n, ... of the item range
 
 struct RayBatchParams {
     const FfRay* rays;

@@ -1294,8 +1294,6 @@ struct Path {
     Ray ray;       // current world-space ray
     float bx, by, bz; // throughput
     float ax, ay, az; // running sum over samples
-    unsigned run_next, run_stride; // work items this lane still owns from its last queue fetch: run_next, run_next + run_stride, ...
-    int run_left;
 };
 
 // kernel.cu:197-205 for global pixel (x, y): origin = camera position, direction through the pixel corner.
@@ -1330,40 +1328,79 @@ __device__ __forceinline__ void start_sample(const KParams& p, Path& P)
     P.bx = P.by = P.bz = 1.f;
 }
 
-// Pull the next traceable pixel from the global queue for every calling lane (wave-wide ballot + prefix compaction
-// among the lanes that execute the call: one atomic per wave and round).  Returns false for lanes that saw the end of
-// the queue.
-__device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& P)
+// The part of the work queue a wave owns: items [next, end).  Wave-uniform (scalar registers).
+struct WaveQueue {
+    unsigned next, end; // in the counter's own numbering (see queue_item)
+    unsigned counter;   // which counter the wave draws from
+    unsigned owned;     // how many items that counter owns
+    bool dry;           // it has nothing left
+};
+
+// The launch's items are dealt to the counters in stripes of kQueueStripe: counter c of n owns the stripes c, c + n, ... so
+// every counter covers the whole image evenly and they run dry together.  Number v of counter c is this item:
+__device__ __forceinline__ unsigned queue_item(const KParams& p, const WaveQueue& Q, unsigned v)
 {
-    bool got = false, exhausted = false;
+    return ((v / kQueueStripe) * (unsigned)p.queue_counters + Q.counter) * kQueueStripe + (v % kQueueStripe);
+}
+
+__device__ __forceinline__ WaveQueue make_wave_queue(const KParams& p)
+{
+    WaveQueue Q;
+    const unsigned n = (unsigned)p.queue_counters, c = blockIdx.x % n;
+    const unsigned stripes = (p.total_items + kQueueStripe - 1) / kQueueStripe;
+    const unsigned mine = stripes > c ? (stripes - c + n - 1) / n : 0u;
+    // the last stripe of the range may be short
+    const unsigned cut = mine > 0u && (stripes - 1u) % n == c ? stripes * kQueueStripe - p.total_items : 0u;
+    Q.next = Q.end = 0u;
+    Q.counter = c;
+    Q.owned = mine * kQueueStripe - cut;
+    Q.dry = Q.owned == 0u;
+    return Q;
+}
+
+// Pull the next traceable pixel for every calling lane.  Two levels: a wave takes a CHUNK of consecutive items from the global
+// counter (one atomic: what its idle lanes ask for, at least queue_chunk items) and deals them to its lanes with no memory
+// traffic; what is left over serves the wave's next requests.  One counter serves about 10^8 atomics a second, each waiting
+// behind the others': a wave asking it for every item held 1-spp frames (two million one-path items) to a third of the
+// saturated rate.  So the launch spreads its waves over several counters in different memory channels (queue_item: each owns
+// an even share of the image; no stealing: they run dry together), and queue_chunk is sized by the host so that a chunk is a
+// few dozen samples of work, whatever the item length.  (Chunks that shrink with what is left - guided self-scheduling, up to a
+// tile of pixels per wave - were measured: the big early chunks unbalance frames whose cost varies across the image, the
+// reference's default camera 191 ms instead of 84.)
+// Called by ALL lanes of the wave (Q must stay wave-uniform); `need` marks the lanes that want a pixel.  Returns false for lanes
+// that did not ask or saw the end of the queue.
+__device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& P, WaveQueue& Q, bool need)
+{
+    bool got = false, exhausted = !need;
     for (;;) {
         const bool want = !got && !exhausted;
-        if (__ballot(want) == 0ull) break;
-        // Lanes that used up their run fetch a new one: one atomic per wave for items_per_fetch items per asking lane,
-        // dealt so that at every step the lanes of the fetch hold consecutive items (base + step * lanes + rank).  With
-        // short items (few samples per pixel) a fetch per item would saturate the counter's memory channel.
-        const bool fetch = want && P.run_left == 0;
-        const unsigned long long m = __ballot(fetch);
-        if (m != 0ull) {
-            const unsigned cnt = (unsigned)__popcll(m);
-            unsigned base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(p.queue, cnt * (unsigned)p.items_per_fetch);
-            base = __shfl(base, leader);
-            if (fetch) {
-                P.run_next = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                P.run_stride = cnt;
-                P.run_left = p.items_per_fetch;
-            }
-        }
-        if (want) {
-            const unsigned item = P.run_next;
-            P.run_next += P.run_stride;
-            --P.run_left;
-            if (item >= p.total_items) {
+        const unsigned long long m = __ballot(want);
+        if (m == 0ull) break;
+        if (Q.next >= Q.end) {
+            if (Q.dry) {
                 exhausted = true;
-                P.run_left = 0;
-            } else {
+                continue;
+            }
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned size = max((unsigned)__popcll(m), p.queue_chunk);
+            unsigned base = 0u;
+            if (lane == leader) base = atomicAdd(p.queue + Q.counter * kQueueStride, size);
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+            if (base >= Q.owned) {
+                Q.dry = true;
+                Q.next = Q.end = Q.owned;
+                continue;
+            }
+            Q.next = base;
+            Q.end = min(base + size, Q.owned);
+        }
+        const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned avail = Q.end - Q.next, asked = (unsigned)__popcll(m);
+        const bool take = want && rank < avail;
+        const unsigned item = queue_item(p, Q, Q.next + rank);
+        Q.next += min(asked, avail);
+        if (take) {
+            {
                 // an item is one sample block of one pixel; pixels walk 8x8 tiles of the local image (padding items and
                 // untraced pixels are consumed and skipped), blocks are the slow index
                 // items [0, tail_first_item): (pixel, whole block), PIXEL-major: a wave's fetch covers the blocks of a few
@@ -1584,9 +1621,6 @@ __device__ __forceinline__ void init_path(Path& P)
     P.bitem = 0; P.send = 0; P.gxy = 0; P.s = 0; P.b = 0;
     P.pdx = P.pdy = 0.f; P.pdz = 1.f;
     P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
-    P.run_next = 0u;
-    P.run_stride = 1u;
-    P.run_left = 0;
     P.bx = P.by = P.bz = 1.f;
     P.ax = P.ay = P.az = 0.f;
 }
@@ -1620,6 +1654,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     Counters cnt = {};
     Path P;
     init_path(P);
+    WaveQueue Q = make_wave_queue(p);
     Segment S;
     S.best = { kInf, -1, -1 };
     S.pend = { kInf, -1, -1 };
@@ -1636,6 +1671,17 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
+    unsigned long long epoch = 0ull;
+    if (STATS && p.timeline) {
+        if (lane == 0) {
+            const unsigned long long seen = atomicCAS(&p.counters[27], 0ull, wave_t0);
+            epoch = seen ? seen : wave_t0;
+        }
+        epoch = __shfl(epoch, 0);
+    }
+    unsigned* const tl_row = STATS && p.timeline ? p.timeline + (size_t)(blockIdx.x * (BLOCK / kWave) + tid / kWave) * kTimelineBuckets : nullptr;
+    int tl_bucket = 0;
+    unsigned tl_count = 0u;
     for (;;) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
@@ -1649,6 +1695,22 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             }
         }
         const bool setup = !inflight || segment_done(L, S);
+        if (STATS && p.timeline) {
+            // every wave keeps its own row of the histogram (plain stores when the bucket changes: atomics on shared buckets
+            // would throttle the launch they are meant to observe); the host adds the rows
+            const int finished = __popcll(__ballot(setup && inflight));
+            if (finished) {
+                const unsigned long long now = wall_clock64();
+                const unsigned long long bb = now > epoch ? (now - epoch) / p.timeline_ticks : 0ull;
+                const int b = bb < (unsigned long long)kTimelineBuckets ? (int)bb : kTimelineBuckets - 1;
+                if (b != tl_bucket) {
+                    if (lane == 0 && tl_count) tl_row[tl_bucket] += tl_count;
+                    tl_bucket = b;
+                    tl_count = 0u;
+                }
+                tl_count += (unsigned)finished;
+            }
+        }
         Best best;
         bool hit = false;
         if (setup && inflight) {
@@ -1665,10 +1727,16 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             inflight = false;
         }
         if (STATS) t2 = __builtin_amdgcn_s_memtime();
-        if (setup && !active && !exhausted) {
-            active = acquire_pixel(p, lane, P);
-            exhausted = !active;
-            if (STATS && exhausted) atomicMax(&p.counters[23], ~(unsigned long long)wall_clock64()); // (complemented) first lane to find the queue empty
+        {
+            const bool need = setup && !active && !exhausted;
+            if (__ballot(need) != 0ull) {
+                const bool got = acquire_pixel(p, lane, P, Q, need); // (all lanes call: the wave's chunk of the queue is wave state)
+                if (need) {
+                    active = got;
+                    exhausted = !got;
+                    if (STATS && exhausted) atomicMax(&p.counters[23], ~(unsigned long long)wall_clock64()); // (complemented) first lane to find the queue empty
+                }
+            }
         }
         if (STATS) t3 = __builtin_amdgcn_s_memtime();
         if (setup && active) {
@@ -1687,6 +1755,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3; tphase[4] += t5 - t4;
         }
     }
+    if (STATS && p.timeline && lane == 0 && tl_count) tl_row[tl_bucket] += tl_count;
     if (STATS && lane == 0) {
         atomicAdd(&p.counters[4], tphase[0]);
         atomicAdd(&p.counters[5], tphase[1]);
@@ -1711,11 +1780,18 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
     Counters cnt = {};
     Path P;
     init_path(P);
+    WaveQueue Q = make_wave_queue(p);
     bool active = false, exhausted = false;
     for (;;) {
-        if (!active && !exhausted) {
-            active = acquire_pixel(p, lane, P);
-            exhausted = !active;
+        {
+            const bool need = !active && !exhausted;
+            if (__ballot(need) != 0ull) {
+                const bool got = acquire_pixel(p, lane, P, Q, need);
+                if (need) {
+                    active = got;
+                    exhausted = !got;
+                }
+            }
         }
         // every thread of the workgroup takes part in staging the triangle batches
         if (__syncthreads_or(active ? 1 : 0) == 0) break;

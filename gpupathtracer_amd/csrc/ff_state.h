@@ -75,7 +75,7 @@ struct FfState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
     int block_threads = ff::kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
-    bool setup_threshold_forced = false, block_threads_forced = false;
+    bool setup_threshold_forced = false;
     int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
@@ -92,6 +92,11 @@ struct FfState {
     bool pending = false;
     // fault injection for tests (FF_DEBUG_FAIL_ALLOC=k: the k-th scene allocation of every upload reports out-of-memory)
     int debug_fail_alloc = -1, alloc_countdown = -1;
+    // FF_DEBUG_TIMELINE_US=bucket: instrumented launches histogram ray completions over the launch's wall clock (ff_debug_timeline)
+    int timeline_bucket_us = 0;
+    unsigned* d_timeline = nullptr;
+    unsigned h_timeline[1024] = {};
+    std::vector<unsigned> h_timeline_rows; // one row per wave, added up by ff_debug_timeline
 };
 
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "ff_scene_info", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
-    "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_check_ieee", "ff_load_obj", "ff_free_triangles",
+    "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_timeline", "ff_debug_check_ieee", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
     "ff_dist_unique_id", "ff_dist_init", "ff_dist_shutdown", "ff_dist_strip_rows", "ff_render_distributed",
     "ff_multi_create", "ff_multi_destroy", "ff_multi_count", "ff_multi_state", "ff_multi_uses_rccl", "ff_multi_upload_scene",
@@ -107,6 +107,7 @@ def load():
     lib.ff_set_collect_stats.argtypes = [vp, i32]
     lib.ff_stats.argtypes = [vp, P(T.FfStats)]
     lib.ff_debug_counters.argtypes = [vp, P(C.c_ulonglong)]
+    lib.ff_debug_timeline.argtypes = [vp, P(C.c_uint), P(C.c_int)]
     lib.ff_debug_kernel_name.argtypes = [vp]
     lib.ff_debug_kernel_name.restype = C.c_char_p
     lib.ff_debug_check_ieee.argtypes = [vp, P(C.c_ulonglong)]
@@ -307,6 +308,13 @@ class Tracer:
         buf = (C.c_ulonglong * 28)()
         check(self._lib.ff_debug_counters(self._state, buf))
         return list(buf)
+
+    def debug_timeline(self):
+        """(bucket_us, counts[1024]): rays completed per wall-clock bucket of the last instrumented launch (FF_DEBUG_TIMELINE_US)."""
+        buf = (C.c_uint * 1024)()
+        us = C.c_int(0)
+        check(self._lib.ff_debug_timeline(self._state, buf, C.byref(us)))
+        return int(us.value), np.frombuffer(buf, dtype=np.uint32).copy()
 
     def render(self, camera, params, want_rgb8=True, want_radiance=True):
         """Headless frame to host numpy arrays: (rgb8 [H,W,3] uint8, radiance [H,W,3] float32)."""

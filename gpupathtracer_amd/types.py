@@ -99,6 +99,10 @@ class FfRenderParams(C.Structure):
     ]
 
 
+FF_STATS_TAIL_ITEMS = 1
+FF_STATS_TAIL_SKIPPED_TOO_LARGE = 2
+
+
 class FfStats(C.Structure):
     _fields_ = [
         ("rays_traced", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("planes_tested", C.c_uint64),

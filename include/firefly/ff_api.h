@@ -255,6 +255,11 @@ FF_API const char* ff_debug_kernel_name(FfState* state);
  * queue empty, first wave start, last wave end. */
 FF_API int ff_debug_counters(FfState* state, unsigned long long* out28);
 
+/* With FF_DEBUG_TIMELINE_US=<bucket> in the environment at ff_create, instrumented renders also count the rays that complete in
+ * each bucket of the (first) launch's wall clock: 1 024 buckets from the start of the first wave, the last one open-ended.
+ * *bucket_us comes back 0 when the histogram is off. */
+FF_API int ff_debug_timeline(FfState* state, unsigned* out1024, int* bucket_us);
+
 /* Self-check of the kernels' arithmetic: their correctly rounded 1/x and sqrt(x) against the compiler's IEEE expansions on
  * every one of the 2^32 float bit patterns; out_mismatches2[0] / [1] must come back 0 (a few milliseconds). */
 FF_API int ff_debug_check_ieee(FfState* state, unsigned long long* out_mismatches2);

@@ -303,6 +303,53 @@ def test_fine_grained_tail_is_bit_identical(monkeypatch):
     assert np.array_equal(rgb8, o_rgb8) and np.array_equal(rad.view(np.uint32), o_rad.view(np.uint32))
 
 
+def test_work_queue_knobs_do_not_change_a_bit(tracer, monkeypatch):
+    """The work queue (csrc/ff_kernels.hip acquire_pixel: several counters that each own every n-th stripe of 64 items, waves that
+    take a chunk per atomic and deal it to their lanes) only decides WHO traces an item: any number of counters and any chunk size
+    give the same frame - every item exactly once - on frames of one and of several launches, with the fine-grained tail, on the
+    strips of a multi-GPU rank and in brute-force mode."""
+    scene = scenes.cornell_wahoo_scene()
+    w, h = 328, 187  # 41 x 24 tiles of 8x8 (the last column and row are ragged), 984 stripes
+    cam = _inside(w, h)
+    tracer.upload_scene(scene)
+    cases = {
+        "1spp": (lib.render_params(w, h, 6, 1, 9), None),
+        "3 blocks": (lib.render_params(w, h, 3, 130, 9), None),
+        "launches": (lib.render_params(w, h, 3, 200, 9, spp_per_launch=64), None),
+        "brute": (lib.render_params(w, h, 2, 1, 9, trace_mode=T.TRACE_BRUTE_FORCE), None),
+        "strips": (lib.render_params(w, h, 3, 70, 9), (8, 1, 3)),
+    }
+
+    def frames():
+        out = {}
+        for name, (p, strips) in cases.items():
+            rgb8, rad = tracer.render(cam, p) if strips is None else tracer.render_strips(cam, p, *strips)
+            out[name] = (rgb8.copy(), rad.view(np.uint32).copy(), tracer.stats().rays_traced)
+        return out
+
+    ref = frames()
+    assert ref["1spp"][1].any()
+    for counters, chunk in (("1", "1"), ("3", "7"), ("16", "64"), ("64", "4096"), ("5", "100")):
+        monkeypatch.setenv("FF_QUEUE_COUNTERS", counters)
+        monkeypatch.setenv("FF_QUEUE_CHUNK", chunk)
+        got = frames()
+        for name in cases:
+            assert got[name][2] == ref[name][2], (counters, chunk, name)
+            assert np.array_equal(got[name][0], ref[name][0]) and np.array_equal(got[name][1], ref[name][1]), (counters, chunk, name)
+    monkeypatch.setenv("FF_TAIL_GROUP", "16")  # (read at ff_create)
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        p = lib.render_params(w, h, 3, 300, 9)
+        monkeypatch.delenv("FF_QUEUE_COUNTERS")
+        monkeypatch.delenv("FF_QUEUE_CHUNK")
+        a = t.render(cam, p)[1].view(np.uint32).copy()
+        monkeypatch.setenv("FF_QUEUE_COUNTERS", "7")
+        monkeypatch.setenv("FF_QUEUE_CHUNK", "33")
+        b = t.render(cam, p)[1].view(np.uint32).copy()
+        assert t.stats().flags & T.FF_STATS_TAIL_ITEMS
+    assert np.array_equal(a, b)
+
+
 def test_tiles_equal_the_full_frame(tracer):
     """ff_render_tile: arbitrary rectangles (ragged sizes, image corners) carry the pixels of the full frame, bit for bit,
     in both shade modes and with enough samples for the fine-grained tail."""
