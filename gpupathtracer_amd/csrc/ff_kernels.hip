@@ -1402,10 +1402,11 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
         if (take) {
             {
                 // an item is one sample block of one pixel; pixels walk 8x8 tiles of the local image (padding items and
-                // untraced pixels are consumed and skipped), blocks are the slow index
-                // items [0, tail_first_item): (pixel, whole block), PIXEL-major: a wave's fetch covers the blocks of a few
-                // pixels, whose sums are neighbours in blocksums[pixel][block] and leave the XCD's L2 as whole lines instead of
-                // one masked 64-byte write per 16-byte sum; beyond: (pixel, sample group) of the tail block, group-major
+                // untraced pixels are consumed and skipped)
+                // items [0, tail_first_item): (pixel, whole block), PIXEL-major: a wave's chunk covers the blocks of one or a few
+                // pixels, whose sums are neighbours in blocksums[pixel][block]: stored by one wave, they meet in one XCD's L2
+                // and leave it as whole lines instead of one masked 64-byte write per 16-byte sum (0.59 instead of 1.93 GB of
+                // HBM writes per 1080p 1 024-spp frame); beyond: (pixel, sample group) of the tail block, group-major
                 const bool tail = p.tail_block >= 0 && item >= p.tail_first_item;
                 const unsigned rel = tail ? item - p.tail_first_item : item;
                 unsigned blk, pitem; // tail: blk is the group index
