@@ -377,30 +377,34 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     }
     FF_HIP(hipMemsetAsync(s->d_counters, 0, (size_t)(1 + k.queue_counters) * kQueueStride * sizeof(unsigned), st)); // counters and the work queue behind them
     FF_HIP(hipEventRecord(s->ev_begin, st));
-    // Fine-grained tail: in the launch that finishes the frame, the last block (if the launch has at least four) is traced
-    // as 16-sample items with per-sample storage (see KParams::tail_samples).
+    // Fine-grained tail: in the launch that finishes the frame, the last sample block is traced as items of a few samples
+    // with per-sample storage (see KParams::tail_samples), so that the launch runs dry on short items.
     k.tail_block = -1;
     const int last_launch_blocks = num_blocks - (launches - 1) * blocks_per_launch;
-    // It pays where a launch is short (a rank of a multi-GPU frame: +3.3 % at eight ranks) and costs a per-sample buffer
-    // (2.1 GB written and read back at 1080p) that a one-GPU frame does not earn back (+0.2 %): on by default only for
-    // multi-part frames; FF_TAIL_GROUP forces it.  Frames whose buffer would pass 4 GiB render without it (FfStats::flags).
-    const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && last_launch_blocks >= 4 &&
-                             s->tail_group_spp < block_spp && (num_parts > 1 || s->tail_forced);
+    // It pays where a launch is short against its items: the ranks of a multi-GPU frame (+3.3 % at eight ranks) and one-GPU
+    // frames of up to eight blocks (1080p C2 with / without, ms: 64 spp 66.0 / 71.4, 128 spp 128.4 / 132.3, 256 spp 247.8 / 251.1).
+    // It costs a per-sample buffer (2.1 GB written and read back at 1080p), which the 1 024-spp one-GPU frame does not earn back
+    // (+0.4 %, and 4x its HBM traffic): off there.  FF_TAIL_GROUP forces it (with that group size) wherever a launch has
+    // FF_TAIL_MIN_BLOCKS blocks.  Frames whose buffer would pass 4 GiB render without it (FfStats::flags).
+    const int tail_n = spp - (num_blocks - 1) * block_spp; // samples of the frame's last block
+    const bool short_frame = num_parts == 1 && !s->tail_forced && num_blocks <= 8;
+    // group size: the given one (multi-part frames: 32 samples), scaled with the block size beyond 1 024 spp and at least an
+    // eighth of the block; short one-GPU frames: a quarter of the block, at least 4 samples
+    const int tail_step = short_frame ? std::max(4, (tail_n + 3) / 4) : std::max(s->tail_group_spp * (block_spp / 64), (tail_n + 7) / 8);
+    const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && tail_step < tail_n &&
+                             (short_frame || ((num_parts > 1 || s->tail_forced) && last_launch_blocks >= s->tail_min_blocks));
     const bool tail_mode = tail_wanted && (uint64_t)k.pix_items * (uint64_t)block_spp * sizeof(float4) <= (4ull << 30); // (also keeps slot indices in 31 bits)
     s->pending_flags = (tail_mode ? FF_STATS_TAIL_ITEMS : 0u) | (tail_wanted && !tail_mode ? FF_STATS_TAIL_SKIPPED_TOO_LARGE : 0u);
     if (tail_mode) {
         int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, (size_t)k.pix_items * (size_t)block_spp * sizeof(float4));
         if (tst != FF_OK) return tst;
         k.tail_samples = s->d_tail_samples;
-        k.tail_samples_in_block = spp - (num_blocks - 1) * block_spp;
-        // Equal groups of tail_group_spp samples (scaled with the block size beyond 1 024 spp), at most eight per block.
+        k.tail_samples_in_block = tail_n;
         // (Grading the groups down to an eighth of a block on multi-GPU ranks was measured: the 8-sample items cost more
         // than the tail they save, 92.3 % instead of 93.3 % of ideal at eight ranks.)
-        const int n = k.tail_samples_in_block;
         int g = 0;
         k.tail_start[0] = 0;
-        const int step = std::max(s->tail_group_spp * (block_spp / 64), (n + 7) / 8);
-        while (k.tail_start[g] < n && g < 8) { k.tail_start[g + 1] = std::min(n, k.tail_start[g] + step); ++g; }
+        while (k.tail_start[g] < tail_n && g < 8) { k.tail_start[g + 1] = std::min(tail_n, k.tail_start[g] + tail_step); ++g; }
         k.tail_groups = g;
     }
     for (int l = 0; l < launches; ++l) {
@@ -493,6 +497,7 @@ int ff_create(FfState** out_state, int device_id)
     }
     if (const char* e = std::getenv("FF_DEBUG_FAIL_ALLOC")) s->debug_fail_alloc = std::atoi(e);
     if (const char* e = std::getenv("FF_DEBUG_TIMELINE_US")) s->timeline_bucket_us = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("FF_TAIL_MIN_BLOCKS")) s->tail_min_blocks = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("FF_TAIL_GROUP")) {
         s->tail_group_spp = std::max(0, std::min(64, std::atoi(e)));
         s->tail_forced = true;

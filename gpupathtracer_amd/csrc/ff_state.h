@@ -60,6 +60,7 @@ struct FfState {
     float4* d_tail_samples = nullptr;
     size_t tail_samples_bytes = 0;
     bool tail_forced = false; // FF_TAIL_GROUP given: the fine-grained tail also for one-part frames
+    int tail_min_blocks = 4;  // launches with fewer sample blocks keep whole-block items (FF_TAIL_MIN_BLOCKS)
     int tail_group_spp = 32; // FF_TAIL_GROUP (0 = off); 32 measured best: 8 ranks +3.3 %, 1 rank +0.2 % (16: +3 % / -1.1 %, 8: +3 % / -5 %)
     // progressive accumulation (ff_render_progressive)
     float* d_accum = nullptr;
