@@ -350,6 +350,34 @@ def test_work_queue_knobs_do_not_change_a_bit(tracer, monkeypatch):
     assert np.array_equal(a, b)
 
 
+def test_launch_timeline_counts_every_ray(monkeypatch):
+    """FF_DEBUG_TIMELINE_US: instrumented launches histogram ray completions over the launch's wall clock (one row per wave,
+    added up by ff_debug_timeline).  Every ray is counted exactly once, and the instrumented frame is the plain frame."""
+    monkeypatch.setenv("FF_DEBUG_TIMELINE_US", "20")
+    scene = scenes.cornell_wahoo_scene()
+    cam = _inside(320, 180)
+    p = lib.render_params(320, 180, 6, 8, 3)
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        plain = t.render(cam, p)[1].view(np.uint32).copy()
+        rays = t.stats().rays_traced
+        t.set_collect_stats(True)
+        inst = t.render(cam, p)[1].view(np.uint32).copy()
+        inst_rays = t.stats().rays_traced
+        us, counts = t.debug_timeline()
+        t.set_collect_stats(False)
+    assert us == 20 and int(counts.sum()) == rays == inst_rays
+    assert counts[0] > 0 or counts[1] > 0  # the launch starts completing rays within its first 40 us
+    assert np.array_equal(plain, inst)
+    monkeypatch.delenv("FF_DEBUG_TIMELINE_US")
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        t.set_collect_stats(True)
+        t.render(cam, p)
+        us, counts = t.debug_timeline()
+    assert us == 0 and not counts.any()
+
+
 def test_tiles_equal_the_full_frame(tracer):
     """ff_render_tile: arbitrary rectangles (ragged sizes, image corners) carry the pixels of the full frame, bit for bit,
     in both shade modes and with enough samples for the fine-grained tail."""
