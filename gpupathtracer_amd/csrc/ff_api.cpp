@@ -385,7 +385,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     // frames of up to eight blocks (1080p C2 with / without, ms: 64 spp 66.0 / 71.4, 128 spp 128.4 / 132.3, 256 spp 247.8 / 251.1).
     // It costs a per-sample buffer (2.1 GB written and read back at 1080p), which the 1 024-spp one-GPU frame does not earn back
     // (+0.4 %, and 4x its HBM traffic): off there.  FF_TAIL_GROUP forces it (with that group size) wherever a launch has
-    // FF_TAIL_MIN_BLOCKS blocks.  Frames whose buffer would pass 4 GiB render without it (FfStats::flags).
+    // FF_TAIL_MIN_BLOCKS blocks.  Frames whose buffer would pass 16 GiB render without it (FfStats::flags).
     const int tail_n = spp - (num_blocks - 1) * block_spp; // samples of the frame's last block
     const bool short_frame = num_parts == 1 && !s->tail_forced && num_blocks <= 8;
     // group size: the given one (multi-part frames: 32 samples), scaled with the block size beyond 1 024 spp and at least an
@@ -393,7 +393,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const int tail_step = short_frame ? std::max(4, (tail_n + 3) / 4) : std::max(s->tail_group_spp * (block_spp / 64), (tail_n + 7) / 8);
     const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && tail_step < tail_n &&
                              (short_frame || ((num_parts > 1 || s->tail_forced) && last_launch_blocks >= s->tail_min_blocks));
-    const bool tail_mode = tail_wanted && (uint64_t)k.pix_items * (uint64_t)block_spp * sizeof(float4) <= (4ull << 30); // (also keeps slot indices in 31 bits)
+    const bool tail_mode = tail_wanted && (uint64_t)k.pix_items * (uint64_t)block_spp * sizeof(float4) <= (16ull << 30); // (also keeps slot indices in 31 bits; C5's ranks at eight GPUs need 4.2 GB)
     s->pending_flags = (tail_mode ? FF_STATS_TAIL_ITEMS : 0u) | (tail_wanted && !tail_mode ? FF_STATS_TAIL_SKIPPED_TOO_LARGE : 0u);
     if (tail_mode) {
         int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, (size_t)k.pix_items * (size_t)block_spp * sizeof(float4));

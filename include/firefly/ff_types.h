@@ -171,7 +171,7 @@ typedef struct FfStats {
     uint64_t scene_bytes_tris;   /* device bytes of triangle records */
 } FfStats;
 #define FF_STATS_TAIL_ITEMS 1u             /* the frame's last sample block was handed out as fine-grained items (multi-part frames) */
-#define FF_STATS_TAIL_SKIPPED_TOO_LARGE 2u /* ... was wanted, but its per-sample buffer would pass 4 GiB: rendered with whole-block items */
+#define FF_STATS_TAIL_SKIPPED_TOO_LARGE 2u /* ... was wanted, but its per-sample buffer would pass 16 GiB: rendered with whole-block items */
 
 /* Which builder produces the BVH (ff_set_builder). */
 typedef enum FfBuilder {
