@@ -7,9 +7,9 @@
 //     and all geometry records are staged ONCE per workgroup into LDS (112-byte nodes: six box planes for four slots + four
 //     links, kept as seven planes of 16-byte quarters so that a wave's reads spread over all banks) and every lane keeps
 //     its traversal stack in LDS (lane-strided: pushes / pops are bank-conflict free; one entry per visited node);
-//   * lanes pull (pixel, sample block) work items from one global counter with a wave-wide ballot + prefix compaction
-//     (several short items per fetch when a frame has few samples per pixel); a lane sums its block's samples in order,
-//     terminated paths regenerate in place, and a combine pass adds a pixel's blocks in order;
+//   * lanes pull (pixel, sample block) work items with a wave-wide ballot + prefix compaction from the wave's own chunk of
+//     the work queue (a chunk per atomic, 16 counters in different memory channels: acquire_pixel); a lane sums its block's
+//     samples in order, terminated paths regenerate in place, and a combine pass adds a pixel's blocks in order;
 //   * traversal is time-sliced: after a budget of inner-node rounds the lanes whose query is complete resolve, shade and
 //     spawn their next ray TOGETHER while the long-tail lanes keep their traversal state; inside a slice the wave
 //     alternates inner-node phases and leaf phases.  This keeps the 64 lanes occupied although neighbouring rays need
