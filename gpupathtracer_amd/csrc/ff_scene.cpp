@@ -6,12 +6,14 @@
 // reference intersects in object space (kernel.cu:138) and ranks hits by world distance (kernel.cu:113-121); the
 // BVH therefore is one object-space tree per mesh and only prunes work, it never changes a computed hit.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "ff_internal.h"
 #include "ff_math.h"
@@ -166,6 +168,42 @@ struct Builder {
         return nleft;
     }
 
+    // Split node `root` of `v` and everything below it (children are appended to `v`).
+    void expand(std::vector<BuildNode>& v, int root)
+    {
+        std::vector<int> todo{ root };
+        while (!todo.empty()) {
+            const int id = todo.back();
+            todo.pop_back();
+            if (split_node(v, id)) {
+                todo.push_back(v[id].left);
+                todo.push_back(v[id].right);
+            }
+        }
+    }
+
+    // One split: false if node `id` of `v` stays a leaf.
+    bool split_node(std::vector<BuildNode>& v, int id)
+    {
+        const int start = v[id].start, count = v[id].count, depth = v[id].depth;
+        const Box box = v[id].box;
+        const int nleft = split(start, count, box, depth);
+        if (nleft <= 0) return false;
+        BuildNode l, r;
+        l.start = start; l.count = nleft; l.depth = depth + 1; l.box = range_box(l.start, l.count);
+        r.start = start + nleft; r.count = count - nleft; r.depth = depth + 1; r.box = range_box(r.start, r.count);
+        const int li = (int)v.size();
+        v.push_back(l);
+        const int ri = (int)v.size();
+        v.push_back(r);
+        v[id].left = li;
+        v[id].right = ri;
+        return true;
+    }
+
+    // Large meshes are built by several threads: the biggest pending subtrees are split one by one until there are enough of
+    // them, then each is finished by one thread in its own node list (their triangle ranges are disjoint), and the lists are
+    // appended in a fixed order.  The tree does not depend on the number of threads: the emitter numbers nodes by their links.
     void build()
     {
         BuildNode root;
@@ -174,25 +212,54 @@ struct Builder {
         root.box = range_box(0, root.count);
         root.depth = 0;
         bn.push_back(root);
-        std::vector<int> todo{ 0 };
-        while (!todo.empty()) {
-            const int id = todo.back();
-            todo.pop_back();
-            const int start = bn[id].start, count = bn[id].count, depth = bn[id].depth;
-            const Box box = bn[id].box;
-            const int nleft = split(start, count, box, depth);
-            if (nleft <= 0) continue; // leaf
-            BuildNode l, r;
-            l.start = start; l.count = nleft; l.depth = depth + 1; l.box = range_box(l.start, l.count);
-            r.start = start + nleft; r.count = count - nleft; r.depth = depth + 1; r.box = range_box(r.start, r.count);
-            const int li = (int)bn.size();
-            bn.push_back(l);
-            const int ri = (int)bn.size();
-            bn.push_back(r);
-            bn[id].left = li;
-            bn[id].right = ri;
-            todo.push_back(li);
-            todo.push_back(ri);
+        int threads = 1;
+        if (root.count >= 65536) threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("FF_BVH_THREADS")) threads = std::max(1, std::min(64, std::atoi(e)));
+        if (threads == 1) {
+            expand(bn, 0);
+            return;
+        }
+        std::vector<int> pending{ 0 };
+        while (pending.size() < (size_t)threads * 8) {
+            size_t big = 0;
+            for (size_t q = 1; q < pending.size(); ++q)
+                if (bn[pending[q]].count > bn[pending[big]].count) big = q;
+            const int id = pending[big];
+            if (bn[id].count < 2048) break;
+            pending.erase(pending.begin() + (long)big);
+            if (split_node(bn, id)) {
+                pending.push_back(bn[id].left);
+                pending.push_back(bn[id].right);
+            }
+        }
+        std::sort(pending.begin(), pending.end());
+        std::vector<std::vector<BuildNode>> subs(pending.size());
+        std::atomic<size_t> next{ 0 };
+        auto work = [&]() {
+            for (size_t q; (q = next.fetch_add(1)) < pending.size();) {
+                subs[q].push_back(bn[pending[q]]);
+                expand(subs[q], 0);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < threads; ++w) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+        for (size_t q = 0; q < pending.size(); ++q) {
+            const std::vector<BuildNode>& sub = subs[q];
+            const int base = (int)bn.size() - 1; // sub[k], k >= 1, becomes bn[base + k]
+            if (sub[0].left >= 0) {
+                bn[pending[q]].left = base + sub[0].left;
+                bn[pending[q]].right = base + sub[0].right;
+            }
+            for (size_t k = 1; k < sub.size(); ++k) {
+                BuildNode n = sub[k];
+                if (n.left >= 0) {
+                    n.left += base;
+                    n.right += base;
+                }
+                bn.push_back(n);
+            }
         }
     }
 };

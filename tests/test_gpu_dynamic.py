@@ -216,6 +216,22 @@ def test_host_built_tree_structure(tracer):
     assert table4[:, 4].sum() == min(table4[:, 1].sum(), table4[0, 5]) or table4[:, 4].sum() <= table4[0, 5]
 
 
+def test_host_builder_threads_do_not_change_the_tree(tracer, monkeypatch):
+    """Meshes of 65 536 triangles and more are built by several host threads (csrc/ff_scene.cpp Builder::build: the big subtrees
+    are finished in parallel and spliced in a fixed order): nodes, triangle records and the derived 4-wide tree are the same
+    bytes for 1, 3 and 16 threads."""
+    scene = scenes.sphere_stress_scene(3)  # 61 440 triangles: below the threshold, so FF_BVH_THREADS forces the threaded path
+    assert scene.triangle_count == 61440
+    out = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("FF_BVH_THREADS", threads)
+        tracer.upload_scene(scene)
+        nodes, tris, table = tracer.download_bvh(len(scene))
+        nodes4, table4 = tracer.download_bvh4(len(scene))
+        out.append((nodes.tobytes(), tris.tobytes(), table.tobytes(), nodes4.tobytes(), table4.tobytes()))
+    assert out[0] == out[1] == out[2]
+
+
 def test_duplicate_centroids_and_degenerate_extent(lbvh_tracer):
     """Identical Morton codes (coincident triangles) and a mesh that is flat in one axis must still give a well-formed tree."""
     tri = np.zeros((1, 24), dtype=np.float32)
