@@ -892,6 +892,7 @@ __device__ __forceinline__ void geom_step(const LDS& L, int num_planes, const Tr
         pop_subtree(L, nodes4, S);
     } else {
         const int floor = S.sp;
+        if (STATS) cnt.no_mesh += 1; // (big scenes: the counter of plane-only queries counts mesh entries instead)
         enter_mesh(L, g, wr, S); // (leaves the cursor alone for a mesh without a tree)
         if (S.mesh == g) {
             S.tl_sp = floor;
@@ -1053,7 +1054,7 @@ __device__ __forceinline__ bool segment_done(const LDS& L, const Segment& S) { r
 // Unfinished lanes keep their state in S and continue on the next call.
 template <bool STATS, class LDS>
 __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr,
-                                                Segment& S, Counters& cnt, int budget, int leaf_threshold, int num_planes = 0)
+                                                Segment& S, Counters& cnt, int budget, int leaf_threshold, int num_planes = 0, int top_rounds = kLoopGuard, int geom_threshold = 64)
 {
     const int limit = budget > 0 ? budget : kLoopGuard;
     int rounds = 0, guard = 0;
@@ -1062,7 +1063,7 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
         if (STATS) ta = __builtin_amdgcn_s_memtime();
         if constexpr (LDS::big) {
             // lanes whose mesh is exhausted resume the geometry tree; lanes on a geometry leaf screen it or enter its mesh
-            for (int top = 0; top < kLoopGuard; ++top) {
+            for (int top = 0; top < top_rounds; ++top) {
                 const bool back = S.cur == kMeshDone, geom = S.cur < 0 && ((~S.cur) & kGeomLeaf) != 0;
                 if (__ballot(back || geom) == 0ull) break;
                 if (back) leave_mesh(L, nodes4, wr, S);
@@ -1084,7 +1085,7 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
             if constexpr (LDS::big) {
                 // enough lanes wait on the geometry tree (a geometry leaf, an exhausted mesh): serve them first; the few lanes
                 // that hold triangles keep them for a fuller leaf phase
-                if (__popcll(__ballot(S.cur == kMeshDone || (S.cur < 0 && !tri_leaf))) >= leaf_threshold) {
+                if (__popcll(__ballot(S.cur == kMeshDone || (S.cur < 0 && !tri_leaf))) >= geom_threshold) {
                     leaves_due = false;
                     break;
                 }
@@ -1750,7 +1751,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (__ballot(inflight) == 0ull) break;
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
         // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
-        if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes);
+        if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes, p.top_rounds, p.geom_threshold);
         if (STATS) {
             const unsigned long long t5 = __builtin_amdgcn_s_memtime();
             tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3; tphase[4] += t5 - t4;

@@ -47,7 +47,7 @@ ir, lr, tr, pr, sr = c[8], c[9], c[10], c[11], c[12]
 budget = os.environ.get("FF_SETUP_THRESHOLD")
 print(f"budget {budget} rays {rays}  kernel_ms {st.kernel_ms:.1f}  Mrays/s {rays / st.kernel_ms / 1e3:.0f}")
 print(f"segments: rounds {sr}  occupancy {rays / (64 * sr):.3f}")
-print(f"planes  : per ray {planes / rays:.2f}   queries without mesh candidates: {c[14] / rays:.3f}   exact plane tests per ray: {c[15] / rays:.4f}   screening rounds/segment-round {pr / max(sr, 1):.2f}")
+print(f"planes  : per ray {planes / rays:.2f}   queries without mesh candidates (big scenes: mesh entries per ray): {c[14] / rays:.3f}   exact plane tests per ray: {c[15] / rays:.4f}   screening rounds/segment-round {pr / max(sr, 1):.2f}")
 print(f"inner   : per ray {nodes / rays:.2f}  rounds/segment-round {ir / sr:.2f}  occupancy {nodes / (64 * ir):.3f}")
 print(f"leaves  : rounds/segment-round {lr / sr:.2f}")
 print(f"tris    : per ray {tris / rays:.2f}  rounds/segment-round {tr / sr:.2f}  occupancy {tris / (64 * tr):.3f}")
