@@ -302,10 +302,6 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.shade_mode = prm->shade_mode;
     k.setup_threshold = s->setup_threshold;
     k.leaf_threshold = s->leaf_threshold;
-    k.top_rounds = 1;
-    k.geom_threshold = s->leaf_threshold;
-    if (const char* e = std::getenv("FF_GEOM_THRESHOLD")) k.geom_threshold = std::max(1, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("FF_TOP_ROUNDS")) k.top_rounds = std::max(1, std::atoi(e));
     k.num_geoms = s->num_geoms;
     k.num_planes = s->num_planes;
     k.num_quads = s->num_quads;

@@ -43,8 +43,6 @@ struct KParams {
     // BVH kernel scheduling knobs: setup_threshold = traversal time slice in inner-node rounds (0 = run every query to
     // completion before the wave shades); leaf_threshold = number of lanes holding a leaf that ends an inner-node phase early
     int setup_threshold, leaf_threshold;
-    int geom_threshold;   // big scenes: number of lanes waiting on the geometry tree (a geometry leaf, an exhausted mesh) that ends an inner-node phase early
-    int top_rounds;       // big scenes: geometry-leaf rounds (screens, mesh entries, mesh exits) served per traversal iteration
     // scene
     int num_geoms;
     int num_planes;  // records [0, num_planes) are analytic shapes (planes, then spheres), the rest meshes (processing order)

@@ -310,7 +310,6 @@ struct LdsBase {
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
     const float4* smooth_normals; // non-null: triangle hits carry the interpolated vertex normal (FF_SHADE_DIFFUSE_PATH_SMOOTH)
-    int last_base;  // first record of the last chunk of 32 geometry records: ((num_geoms - 1) / 32) * 32
     // Scenes of more than 32 geometries ("big", a compile-time property of the kernel instantiation): the records stay in
     // global memory (L1/L2) and a query finds its candidates by walking a tree over the geometries' world boxes (tlas).
     // The geometry tree is a 4-wide tree like the meshes' (same nodes, same inner step, in WORLD space); its leaves are
@@ -330,8 +329,7 @@ struct LdsT : LdsBase {
 
 template <int BIG = 0>
 __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
-                                              int last_base = 0, const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0,
-                                              int top_lds_count = 0)
+                                              const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0, int top_lds_count = 0)
 {
     LdsT<BIG> L;
     L.geoms_g = reinterpret_cast<const float4*>(geoms);
@@ -340,7 +338,6 @@ __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int
     L.top_lds_count = top_lds_count;
     L.num_quads = num_quads;
     L.smooth_normals = smooth_normals;
-    L.last_base = last_base;
     L.node_cap = node_cap;
     L.stride = block;
     L.stack_base = node_cap * (kNodeVec4 * 4) + tid;
@@ -488,8 +485,7 @@ struct Pending {
 struct Segment {
     BestId best;
     Pending pend;
-    unsigned meshes;           // candidate meshes not started yet (bit = record index - base)
-    int base;                  // first geometry record of the chunk of 32 the query is working on (0 unless the scene has > 32)
+    unsigned meshes;           // candidate meshes not started yet (bit = record index; scenes of up to 32 geometries)
     int cur, sp, mesh;         // traversal cursor (4-wide node relative to the mesh's root >= 0, leaf < 0, kDone), stack height, record index of the current mesh
     int tl_sp;                 // big scenes, while a mesh is being traversed: stack entries [0, tl_sp) are the pending entries of the
                                // geometry tree, the mesh's own entries sit above them (0 otherwise)
@@ -668,19 +664,17 @@ __device__ __forceinline__ void screen_analytic(const LDS& L, int g, const TriRe
 
 // Start a closest-hit query: test every plane (fast form) and remember which meshes the ray can reach.
 //
-// Planes are screened in a wave-uniform loop (records through scalar loads, all lanes busy) WITHOUT the IEEE sqrt/divide
+// Planes are pre-filtered by their world boxes in a wave-uniform loop, then screened per lane WITHOUT the IEEE sqrt/divide
 // of kernel.cu:138: the hit position on the unit quad does not depend on the length of the object-space direction, so
 // the screen works on the un-normalised direction M^-1*d, for which the ray parameter is the world-space parameter.
 // Anything within the margins (quad edges, t ~ 0, |n.d| ~ 1e-7) is decided by the exact reference test at once.
-// One chunk of up to 32 geometry records starting at S.base: screen its planes / spheres and collect its candidate meshes.
-// Scenes of up to 32 geometries (the reference has 5) are a single chunk; larger scenes are worked through chunk by chunk,
-// each query carrying its best / pending candidate across chunks.
+// Scenes of up to 32 geometries (the reference has 5): every query screens all planes / spheres and collects its candidate meshes
+// in a bit mask (larger scenes walk the geometry tree instead: enter_top / geom_step).
 template <bool STATS, class LDS>
-__device__ __forceinline__ void scan_chunk(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+__device__ __forceinline__ void scan_records(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                            const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
-    const int base = S.base;
-    const int prim_end = min(num_planes, base + 32), geom_end = min(num_geoms, base + 32);
+    const int prim_end = num_planes, geom_end = num_geoms;
     const float wlen = __builtin_amdgcn_rcpf(inv_length(wr)); // |world direction| (1 for the integrator's rays)
 
     // Stage 1, wave-uniform: which quads can the ray reach at all?  The padded world box of a quad is flat, so for the
@@ -689,15 +683,15 @@ __device__ __forceinline__ void scan_chunk(const LDS& L, const GeomRecord* __res
     if (STATS) tb0 = __builtin_amdgcn_s_memtime();
     const WorldSlab ws = make_world_slab(wr);
     unsigned quads = 0u;
-    for (int g = base; g < prim_end; ++g) {
+    for (int g = 0; g < prim_end; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-        if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << (g - base);
+        if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << g;
     }
     if (STATS) tb1 = __builtin_amdgcn_s_memtime();
     // Stage 2, per lane: screen the lane's own candidates (records from the LDS copy at per-lane addresses).
     for (int guard = 0; __ballot(quads != 0u) != 0ull && guard < 32; ++guard) {
         if (quads == 0u) continue;
-        const int g = base + __ffs((int)quads) - 1;
+        const int g = __ffs((int)quads) - 1;
         quads &= quads - 1u;
         screen_analytic<STATS>(L, g, tris, wr, wlen, S, cnt);
     }
@@ -706,9 +700,9 @@ __device__ __forceinline__ void scan_chunk(const LDS& L, const GeomRecord* __res
     // meshes: conservative world-box test against what the planes already found
     S.meshes = 0u;
     const float limit = fminf(S.best.dist, S.pend.dist);
-    for (int g = max(num_planes, base); g < geom_end; ++g) {
+    for (int g = num_planes; g < geom_end; ++g) {
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << (g - base);
+        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << g;
     }
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
     if (STATS) {
@@ -720,7 +714,7 @@ __device__ __forceinline__ void scan_chunk(const LDS& L, const GeomRecord* __res
 template <class LDS>
 __device__ __forceinline__ void enter_top(const LDS& L, const Ray& wr, Segment& S);
 
-// Start a closest-hit query: empty candidate slots, then the first chunk of geometry records.
+// Start a closest-hit query: empty candidate slots, then the geometry records (small scenes) or the root of the geometry tree.
 template <bool STATS, class LDS>
 __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                               const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
@@ -736,7 +730,6 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __
     S.tl_sp = 0;
     S.mesh = -1;
     S.resume = 0;
-    S.base = 0;
     if constexpr (LDS::big) {
         // big scenes: the query starts at the root of the tree over the geometries, in world space
         S.meshes = 0u;
@@ -744,7 +737,7 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __
         S.cur = 0;
         return;
     }
-    scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+    scan_records<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
 }
 
 // Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
@@ -836,7 +829,7 @@ __device__ __forceinline__ void enter_mesh(const LDS& L, int g, const Ray& wr, S
 template <class LDS>
 __device__ __forceinline__ void start_next_mesh(const LDS& L, const Ray& wr, Segment& S)
 {
-    const int g = S.base + __ffs((int)S.meshes) - 1;
+    const int g = __ffs((int)S.meshes) - 1;
     S.meshes &= S.meshes - 1u;
     enter_mesh(L, g, wr, S);
 }
@@ -1044,17 +1037,15 @@ __device__ __forceinline__ void finish_segment(const LDS& L, const TriRecord* __
     best.cx = H.cx; best.cy = H.cy; best.cz = H.cz;
 }
 
-// Nothing left to do in the current chunk of geometry records / in the whole query.
-__device__ __forceinline__ bool chunk_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
-template <class LDS>
-__device__ __forceinline__ bool segment_done(const LDS& L, const Segment& S) { return chunk_done(S) && S.base >= L.last_base; }
+// Nothing left to do in the query.
+__device__ __forceinline__ bool segment_done(const Segment& S) { return S.cur == kDone && S.meshes == 0u && S.resume == 0; }
 
 // Advance the queries of the calling lanes: mesh starts, inner-node phases, leaf phases and near-tie resolutions alternate
 // wave-wide until every calling lane is done or `budget` inner-node rounds have been spent (budget <= 0: no limit).
 // Unfinished lanes keep their state in S and continue on the next call.
 template <bool STATS, class LDS>
 __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr,
-                                                Segment& S, Counters& cnt, int budget, int leaf_threshold, int num_planes = 0, int top_rounds = kLoopGuard, int geom_threshold = 64)
+                                                Segment& S, Counters& cnt, int budget, int leaf_threshold, int num_planes = 0)
 {
     const int limit = budget > 0 ? budget : kLoopGuard;
     int rounds = 0, guard = 0;
@@ -1062,12 +1053,15 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
         unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
         if (STATS) ta = __builtin_amdgcn_s_memtime();
         if constexpr (LDS::big) {
-            // lanes whose mesh is exhausted resume the geometry tree; lanes on a geometry leaf screen it or enter its mesh
-            for (int top = 0; top < top_rounds; ++top) {
+            // lanes whose mesh is exhausted resume the geometry tree; lanes on a geometry leaf screen it or enter its mesh.
+            // ONE round per iteration: a lane that pops straight into another geometry leaf waits for the next quorum instead of
+            // being served with the two or three others in its situation (108 geometries: +5 %, 258: +8 %).
+            {
                 const bool back = S.cur == kMeshDone, geom = S.cur < 0 && ((~S.cur) & kGeomLeaf) != 0;
-                if (__ballot(back || geom) == 0ull) break;
-                if (back) leave_mesh(L, nodes4, wr, S);
-                else if (geom) geom_step<STATS>(L, num_planes, tris, nodes4, wr, S, cnt);
+                if (__ballot(back || geom) != 0ull) {
+                    if (back) leave_mesh(L, nodes4, wr, S);
+                    else if (geom) geom_step<STATS>(L, num_planes, tris, nodes4, wr, S, cnt);
+                }
             }
         } else {
             while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
@@ -1085,7 +1079,7 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
             if constexpr (LDS::big) {
                 // enough lanes wait on the geometry tree (a geometry leaf, an exhausted mesh): serve them first; the few lanes
                 // that hold triangles keep them for a fuller leaf phase
-                if (__popcll(__ballot(S.cur == kMeshDone || (S.cur < 0 && !tri_leaf))) >= geom_threshold) {
+                if (__popcll(__ballot(S.cur == kMeshDone || (S.cur < 0 && !tri_leaf))) >= leaf_threshold) {
                     leaves_due = false;
                     break;
                 }
@@ -1123,11 +1117,6 @@ __device__ __forceinline__ void closest_hit_deferred(const LDS& L, const GeomRec
     if (STATS) probe_round(cnt.segment_rounds);
     begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
     traverse_budget<STATS>(L, tris, nodes4, wr, S, cnt, 0, 64, num_planes);
-    while (S.base < L.last_base) { // > 32 geometries: the remaining chunks of records (uniform: every lane walks all chunks)
-        S.base += 32;
-        scan_chunk<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
-        traverse_budget<STATS>(L, tris, nodes4, wr, S, cnt, 0, 64);
-    }
     finish_segment(L, tris, wr, S, best);
     cnt.rays += 1;
 }
@@ -1637,15 +1626,15 @@ __device__ __forceinline__ void init_path(Path& P)
 // EXTRAS = false is the instantiation for scenes made of what the reference itself renders (planes and meshes, diffuse
 // and emitting surfaces): the plane/sphere boundary becomes a compile-time "never" and the MIRROR / GLASS branches of the
 // shader drop out (together they cost the reference-like scenes 3.5 % otherwise, measured on one box).
-// BIG = true (with EXTRAS) is the instantiation for scenes of more than 32 geometries: records read from global memory,
-// candidates found by walking the tree over the geometries (advance_top) instead of scanning all records.
+// BIG = 1 / 2 (with EXTRAS) are the instantiations for scenes of more than 32 geometries: candidates found by walking the tree
+// over the geometries (enter_top / geom_step) instead of scanning all records; 2: records read from global memory.
 template <bool STATS, int BLOCK, bool EXTRAS, int BIG = 0>
 __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
-                                      EXTRAS && !BIG ? ((p.num_geoms - 1) >> 5) << 5 : 0, p.geoms, p.top_first, p.top_lds_first, p.top_lds_count);
+                                      p.geoms, p.top_first, p.top_lds_first, p.top_lds_count);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (p.debug_lds_words != 0u) {
         for (unsigned i = tid; i < p.debug_lds_words; i += BLOCK) reinterpret_cast<unsigned*>(ff_smem)[i] = p.debug_lds_pattern;
@@ -1666,7 +1655,6 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.ix = S.iy = S.iz = S.ox = S.oy = S.oz = 0.f;
     S.scale = 1.f;
     S.tbound = 0.f;
-    S.base = 0;
     S.node_base = 0; S.lds_first = 0; S.lds_count = 0; S.tl_sp = 0;
     S.pnx = 0; S.pny = 1; S.pnz = 2; S.pfx = 3; S.pfy = 4; S.pfz = 5;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
@@ -1688,15 +1676,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         // Lanes whose query is finished (or that have none) resolve + shade + spawn together; lanes still traversing skip.
-        if (EXTRAS && L.last_base > 0) {
-            // scenes of more than 32 geometries: queries that finished a chunk of records move on to the next one
-            const bool advance = inflight && chunk_done(S) && S.base < L.last_base;
-            if (__ballot(advance) != 0ull && advance) {
-                S.base += 32;
-                scan_chunk<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
-            }
-        }
-        const bool setup = !inflight || segment_done(L, S);
+        const bool setup = !inflight || segment_done(S);
         if (STATS && p.timeline) {
             // every wave keeps its own row of the histogram (plain stores when the bucket changes: atomics on shared buckets
             // would throttle the launch they are meant to observe); the host adds the rows
@@ -1751,7 +1731,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (__ballot(inflight) == 0ull) break;
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
         // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
-        if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes, p.top_rounds, p.geom_threshold);
+        if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes);
         if (STATS) {
             const unsigned long long t5 = __builtin_amdgcn_s_memtime();
             tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3; tphase[4] += t5 - t4;
@@ -1815,8 +1795,8 @@ template <int MODE, int BIG = 0>
 __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatchParams p)
 {
     const int tid = threadIdx.x;
-    const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, BIG ? 0 : ((p.num_geoms - 1) >> 5) << 5, p.geoms,
-                                      p.top_first, p.top_lds_first, p.top_lds_count);
+    const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, p.geoms, p.top_first, p.top_lds_first,
+                                      p.top_lds_count);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (MODE == FF_TRACE_BVH) stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);
