@@ -393,10 +393,11 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const int tail_step = short_frame ? std::max(4, (tail_n + 3) / 4) : std::max(s->tail_group_spp * (block_spp / 64), (tail_n + 7) / 8);
     const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && tail_step < tail_n &&
                              (short_frame || ((num_parts > 1 || s->tail_forced) && last_launch_blocks >= s->tail_min_blocks));
-    const bool tail_mode = tail_wanted && (uint64_t)k.pix_items * (uint64_t)block_spp * sizeof(float4) <= (16ull << 30); // (also keeps slot indices in 31 bits; C5's ranks at eight GPUs need 4.2 GB)
+    const size_t tail_bytes = (size_t)k.pix_items * (size_t)tail_n * sizeof(float4); // [sample of the block][pixel item]
+    const bool tail_mode = tail_wanted && tail_bytes <= (16ull << 30); // (also keeps slot indices in 31 bits; C5's ranks at eight GPUs need 4.2 GB)
     s->pending_flags = (tail_mode ? FF_STATS_TAIL_ITEMS : 0u) | (tail_wanted && !tail_mode ? FF_STATS_TAIL_SKIPPED_TOO_LARGE : 0u);
     if (tail_mode) {
-        int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, (size_t)k.pix_items * (size_t)block_spp * sizeof(float4));
+        int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, tail_bytes);
         if (tst != FF_OK) return tst;
         k.tail_samples = s->d_tail_samples;
         k.tail_samples_in_block = tail_n;

@@ -352,7 +352,7 @@ def test_work_queue_knobs_do_not_change_a_bit(tracer, monkeypatch):
 
 def test_stats_flags_report_the_tail_policy(tracer):
     """FfStats::flags: short one-GPU frames use the fine-grained tail, the 1 024-spp frame does not, and a frame whose
-    per-sample buffer would pass 16 GiB says that it went without (31 M pixels x 64 slots x 16 B)."""
+    per-sample buffer would pass 16 GiB says that it went without (31 M pixels x 64 samples x 16 B)."""
     tracer.upload_scene(scenes.cornell_wahoo_scene())
     tracer.render(_inside(320, 180), lib.render_params(320, 180, 3, 8, 1), want_rgb8=False, want_radiance=False)
     assert tracer.stats().flags == T.FF_STATS_TAIL_ITEMS
@@ -360,9 +360,9 @@ def test_stats_flags_report_the_tail_policy(tracer):
     assert tracer.stats().flags == 0
     tracer.render(_inside(64, 36), lib.render_params(64, 36, 2, 1, 1), want_rgb8=False, want_radiance=False)
     assert tracer.stats().flags == 0  # one sample: nothing to split
-    tracer.render(_inside(7680, 4096), lib.render_params(7680, 4096, 2, 8, 1), want_rgb8=False, want_radiance=False)
+    tracer.render(_inside(7680, 4096), lib.render_params(7680, 4096, 1, 64, 1), want_rgb8=False, want_radiance=False)
     assert tracer.stats().flags == T.FF_STATS_TAIL_SKIPPED_TOO_LARGE
-    assert tracer.stats().rays_traced >= 7680 * 4096 * 8
+    assert tracer.stats().rays_traced == 7680 * 4096 * 64
 
 
 def test_launch_timeline_counts_every_ray(monkeypatch):
