@@ -356,14 +356,16 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         // held every frame of short items far below the saturated rate (1080p C2, before -> after: the reference's own 1-ray frame
         // 0.40 -> 0.19 ms, path-traced 1 spp 2.98 -> 1.33 ms, 4 spp 7.3 -> 4.8, 16 spp 20.8 -> 18.0; the 1 024-spp frame from the
         // reference's default camera, whose 64-sample items are mostly one-ray paths, 164 -> 84 ms).  With 16 counters the chunk
-        // hardly matters between 8 and 64 items (profiles/r02_q_queue_sweep.txt); it is sized to 64 samples of work, and launches that give
-        // every lane many items take 16 (1 024 spp: 969 / 965 / 958 ms with 1 / 4 / 16); what a wave holds back at the end of
-        // a launch is its tail (64 spp: 69.5 / 70.1 / 70.8 ms with 1 / 4 / 16; 128 and more cost 5-30 % everywhere).
+        // hardly matters for the atomics between 8 and 64 items (profiles/r02_q_queue_sweep.txt); what it decides is WHICH items a
+        // wave's lanes hold.  Whole 64-sample blocks: 64 items, i.e. the blocks of four neighbouring pixels (one 8x8 tile when a
+        // pixel has one block): the lanes' rays start from the same few surface points and walk the same corner of the trees
+        // (1 024 spp, ms with chunks of 4 / 16 / 64 / 128: C4, whose tree lives in L2, 570 / 530 / 491 / 488; C2 977 / 968 / 956 /
+        // 959; at 64-512 spp C4 gains 10-14 %, C2 1-2 %: profiles/r02_y_chunk_sweep_whole_blocks.txt).  Shorter items (frames of a few samples): 64
+        // samples of work, at most 32 items; there what a wave holds back at the end of the launch counts (1 spp: 1.33 ms with
+        // 16-32, 1.36 with 64).
         const int samples_per_item = std::max(1, std::min(k.block_spp, k.spp_total));
-        const uint64_t items = (uint64_t)k.pix_items * (uint64_t)std::min(num_blocks, blocks_per_launch);
-        const uint64_t items_per_lane = items / ((uint64_t)grid * (uint64_t)block_threads);
-        const int by_item = std::min(32, std::max(4, 64 / samples_per_item)), by_launch = (int)std::min<uint64_t>(16, items_per_lane / 8);
-        k.queue_chunk = (unsigned)std::max(by_item, by_launch);
+        // (the strips of a multi-GPU rank: 32; slowest of eight ranks 125.5 ms against 126.9 with 64 and 125.9 with 16)
+        k.queue_chunk = samples_per_item >= 64 ? (num_parts > 1 ? 32u : 64u) : (unsigned)std::min(32, std::max(4, 64 / samples_per_item));
         if (const char* e = std::getenv("FF_QUEUE_CHUNK")) k.queue_chunk = (unsigned)std::max(1, std::min(4096, std::atoi(e)));
         k.queue_counters = std::min(kQueueCountersDefault, grid);
         if (const char* e = std::getenv("FF_QUEUE_COUNTERS")) k.queue_counters = std::max(1, std::min(std::min(kQueueCounters, grid), std::atoi(e)));
