@@ -28,6 +28,7 @@ void free_scene(FfState* s)
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_nodes4) (void)hipFree(s->d_nodes4);
     s->top_count = s->top_depth = 0;
+    s->num_scan = 0;
     if (s->d_parent) (void)hipFree(s->d_parent);
     s->d_nodes4 = nullptr;
     s->num_nodes4 = s->max_depth4 = 0;
@@ -143,7 +144,8 @@ int finalize_layout(FfState* s)
     if (s->num_geoms > kChunkGeometries) {
         std::vector<BvhNode> top2;
         std::vector<Bvh4Node> top4;
-        build_geometry_tree(s->h_geoms, top2);
+        s->num_scan = std::getenv("FF_NO_SCAN_PLANES") ? 0 : count_scan_planes(s->h_geoms, s->num_quads);
+        build_geometry_tree(s->h_geoms, top2, s->num_scan);
         s->top_depth = collapse_geometry_tree(top2, top4);
         s->top_count = (int)top4.size();
         if (top4.size() > (size_t)s->num_geoms) return fail(FF_ERR_HIP, "geometry tree of %zu nodes for %d geometries", top4.size(), s->num_geoms);
@@ -330,6 +332,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.top_first = (int)s->node_capacity;
     k.top_lds_first = 0;
     k.top_lds_count = s->top_lds_count;
+    k.num_scan = s->num_scan;
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
@@ -1126,6 +1129,7 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.top_first = (int)s->node_capacity;
     p.top_lds_first = 0;
     p.top_lds_count = s->top_lds_count;
+    p.num_scan = s->num_scan;
     p.lds_nodes = s->lds_cap; // (the records' LDS shares were laid out for the trace kernel's workgroup; 512 threads leave more room, never less)
     e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);

@@ -128,7 +128,9 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
 // nodes[0] is the root; link >= 0: node index, link < 0: ~(record index).  Surface-area-heuristic splits
 // (sweep over all three axes: large boxes such as a room's walls are peeled off near the root; median splits below binary
 // depth 24, so the depth stays bounded), one geometry per leaf.  Needs at least two records.  Returns the depth (nodes on the longest root-to-leaf path).
-int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes);
+int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes, int first); // over the records [first, n)
+constexpr int kMaxScanPlanes = 8;
+int count_scan_planes(const std::vector<GeomRecord>& geoms, int num_quads);
 
 // The same tree in the 4-wide form the trace kernels traverse (gpu_collapse_mesh's rule: every binary node at even depth
 // becomes a 4-wide node holding its grandchildren), level by level, links relative to node 0, a geometry as

@@ -51,6 +51,7 @@ struct KParams {
     const GeomRecord* geoms;
     const TriRecord* tris;
     const float4* trinormals; // vertex normals (3 float4 per triangle, parallel to tris); null unless FF_SHADE_DIFFUSE_PATH_SMOOTH
+    int num_scan;           // big scenes: the records [0, num_scan) are planes kept out of the geometry tree, screened first by every query
     const Bvh4Node* nodes4; // the 4-wide trees of all meshes (each mesh's nodes contiguous, level by level, links relative to its root)
     // scenes of more than kChunkGeometries geometries: the 4-wide tree over the geometries' padded world boxes sits in nodes4
     // from top_first on (leaf link = ~(0x40000000 | record index)); its first top_lds_count nodes are cached in LDS at
@@ -104,6 +105,7 @@ struct RayBatchParams {
     int top_first, top_lds_first, top_lds_count;
     int lds_nodes;
     int stack_depth;
+    int num_scan;
 };
 
 // LDS bytes the BVH kernels need for (lds_nodes, stack_depth).

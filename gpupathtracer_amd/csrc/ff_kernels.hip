@@ -316,6 +316,7 @@ struct LdsBase {
     // geometries: link = ~(kGeomLeaf | record index).
     const float4* geoms_g;
     int top_first, top_lds_first, top_lds_count; // its first node in the node array and its share of the LDS node slots
+    int num_scan; // ... and the records [0, num_scan) are planes that stay out of that tree (the walls of a room): every query screens them first
 };
 // (`big` is part of the TYPE, not a field: with a field the optimiser meets a select between an LDS and a global pointer in
 // the record accessors before it has folded the flag, and this compiler crashes on it.)
@@ -329,9 +330,11 @@ struct LdsT : LdsBase {
 
 template <int BIG = 0>
 __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
-                                              const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0, int top_lds_count = 0)
+                                              const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0, int top_lds_count = 0,
+                                              int num_scan = 0)
 {
     LdsT<BIG> L;
+    L.num_scan = num_scan;
     L.geoms_g = reinterpret_cast<const float4*>(geoms);
     L.top_first = top_first;
     L.top_lds_first = top_lds_first;
@@ -714,6 +717,27 @@ __device__ __forceinline__ void scan_records(const LDS& L, const GeomRecord* __r
 template <class LDS>
 __device__ __forceinline__ void enter_top(const LDS& L, const Ray& wr, Segment& S);
 
+// Big scenes: the planes kept out of the geometry tree (records [0, num_scan); host: count_scan_planes), screened like the planes
+// of a small scene - world-box pre-filter in a wave-uniform loop, then every lane screens its own candidates - before the walk
+// through the tree starts: the wall the ray ends on bounds that walk from its first node.
+template <bool STATS, class LDS>
+__device__ __forceinline__ void scan_walls(const LDS& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+{
+    const float wlen = __builtin_amdgcn_rcpf(inv_length(wr));
+    const WorldSlab ws = make_world_slab(wr);
+    unsigned prims = 0u;
+    for (int g = 0; g < L.num_scan; ++g) {
+        const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
+        if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) prims |= 1u << g;
+    }
+    for (int guard = 0; __ballot(prims != 0u) != 0ull && guard < 8; ++guard) {
+        if (prims == 0u) continue;
+        const int g = __ffs((int)prims) - 1;
+        prims &= prims - 1u;
+        screen_analytic<STATS>(L, g, tris, wr, wlen, S, cnt);
+    }
+}
+
 // Start a closest-hit query: empty candidate slots, then the geometry records (small scenes) or the root of the geometry tree.
 template <bool STATS, class LDS>
 __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
@@ -733,6 +757,7 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __
     if constexpr (LDS::big) {
         // big scenes: the query starts at the root of the tree over the geometries, in world space
         S.meshes = 0u;
+        if (L.num_scan > 0) scan_walls<STATS>(L, tris, wr, S, cnt);
         enter_top(L, wr, S);
         S.cur = 0;
         return;
@@ -1634,7 +1659,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
-                                      p.geoms, p.top_first, p.top_lds_first, p.top_lds_count);
+                                      p.geoms, p.top_first, p.top_lds_first, p.top_lds_count, BIG ? p.num_scan : 0);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (p.debug_lds_words != 0u) {
         for (unsigned i = tid; i < p.debug_lds_words; i += BLOCK) reinterpret_cast<unsigned*>(ff_smem)[i] = p.debug_lds_pattern;
@@ -1796,7 +1821,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
 {
     const int tid = threadIdx.x;
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, p.geoms, p.top_first, p.top_lds_first,
-                                      p.top_lds_count);
+                                      p.top_lds_count, BIG ? p.num_scan : 0);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (MODE == FF_TRACE_BVH) stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);

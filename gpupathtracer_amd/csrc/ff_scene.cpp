@@ -446,12 +446,14 @@ int build_top(std::vector<TopItem>& items, int first, int last, std::vector<BvhN
 
 } // namespace
 
-int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes)
+static double box_half_area(const float* mn, const float* mx);
+
+int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNode>& nodes, int first)
 {
     nodes.clear();
-    std::vector<TopItem> items(geoms.size());
-    for (size_t i = 0; i < geoms.size(); ++i) {
-        TopItem& it = items[i];
+    std::vector<TopItem> items(geoms.size() - (size_t)first);
+    for (size_t i = (size_t)first; i < geoms.size(); ++i) {
+        TopItem& it = items[i - (size_t)first];
         it.record = (int)i;
         for (int k = 0; k < 3; ++k) {
             it.mn[k] = geoms[i].wmin[k];
@@ -465,6 +467,32 @@ int build_geometry_tree(const std::vector<GeomRecord>& geoms, std::vector<BvhNod
     nodes.reserve(geoms.size());
     build_top(items, 0, (int)items.size(), nodes, 0, &depth, mn, mx);
     return depth;
+}
+
+static double box_half_area(const float* mn, const float* mx)
+{
+    const double dx = std::max(0.0, (double)std::min(mx[0], 1.0e30f) - (double)std::max(mn[0], -1.0e30f));
+    const double dy = std::max(0.0, (double)std::min(mx[1], 1.0e30f) - (double)std::max(mn[1], -1.0e30f));
+    const double dz = std::max(0.0, (double)std::min(mx[2], 1.0e30f) - (double)std::max(mn[2], -1.0e30f));
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Scenes that walk the geometry tree: the planes whose world boxes span a good part of the scene (the walls of a room) stay
+// OUT of the tree and are screened first by every query, like the planes of a small scene: their boxes would overlap every
+// subtree, and the wall a ray ends on bounds the walk through everything else from its first node.  The records hold the
+// planes largest first (compile_scene), so these are the leading records: returns how many (at most kMaxScanPlanes, and
+// the tree keeps at least two geometries).
+int count_scan_planes(const std::vector<GeomRecord>& geoms, int num_quads)
+{
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (const GeomRecord& r : geoms) {
+        if (!(r.wmin[0] <= r.wmax[0])) continue;
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], r.wmin[k]); mx[k] = std::max(mx[k], r.wmax[k]); }
+    }
+    const double scene = box_half_area(mn, mx);
+    int n = 0;
+    while (n < num_quads && n < kMaxScanPlanes && n + 2 < (int)geoms.size() && scene > 0.0 && box_half_area(geoms[n].wmin, geoms[n].wmax) >= 0.08 * scene) ++n;
+    return n;
 }
 
 int collapse_geometry_tree(const std::vector<BvhNode>& binary, std::vector<Bvh4Node>& out)
@@ -634,7 +662,11 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
     std::stable_sort(out.geoms.begin(), out.geoms.end(), [](const GeomRecord& a, const GeomRecord& b) {
         const bool pa = a.type != FF_GEOM_TRIANGLEMESH, pb = b.type != FF_GEOM_TRIANGLEMESH;
         if (pa != pb) return pa;
-        if (pa) return a.type == FF_GEOM_PLANE && b.type != FF_GEOM_PLANE; // planes before spheres
+        if (pa) {
+            if (a.type != b.type) return a.type == FF_GEOM_PLANE; // planes before spheres
+            // planes: largest world box first (the walls of a room lead the records: count_scan_planes)
+            return a.type == FF_GEOM_PLANE && box_half_area(a.wmin, a.wmax) > box_half_area(b.wmin, b.wmax);
+        }
         return a.tri_count < b.tri_count;
     });
     return FF_OK;

@@ -21,6 +21,7 @@ struct FfState {
     ff::TriRecord* d_tris = nullptr;
     ff::TriNormals* d_normals = nullptr; // vertex normals, parallel to d_tris
     ff::BvhNode* d_nodes = nullptr;   // binary trees: what the builders write and refit works on
+    int num_scan = 0;                  // big scenes: leading plane records kept out of the geometry tree (count_scan_planes)
     ff::Bvh4Node* d_nodes4 = nullptr; // 4-wide trees derived from them (gpu_collapse_mesh): what the trace kernels traverse;
                                       // mesh i's nodes start at its binary slot's index (slots[i].node_first)
     int num_geoms = 0, num_planes = 0, num_quads = 0, num_nodes = 0, max_depth = 0;
