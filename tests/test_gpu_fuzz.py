@@ -73,6 +73,62 @@ def test_five_hundred_geometries_equal_brute_force_and_oracle(tracer):
     assert np.array_equal(again[1].view(np.uint32), rad.view(np.uint32))
 
 
+@pytest.mark.parametrize("walls,crowd", [(3, 40), (8, 30), (12, 33), (34, 2)])
+def test_big_scenes_with_walls_screened_first(tracer, walls, crowd):
+    """Scenes of more than 32 geometries keep the planes that span a good part of the scene out of the geometry tree (at most eight,
+    largest first; csrc/ff_scene.cpp count_scan_planes) and screen them before the walk through the tree: with fewer walls than the
+    cap, exactly the cap, more than the cap (the rest stay in the tree) and almost nothing but walls, the frame equals the
+    brute-force loop's bit for bit, with and without the split (FF_NO_SCAN_PLANES), and ff_intersect_rays agrees with the oracle."""
+    from oracle_lib import oracle_intersect
+    rng = np.random.default_rng(100 + walls)
+    cube = scenes.load_mesh("cube")
+    s = scenes.Scene()
+    for i in range(walls):  # big quads through and around the room, some of them overlapping, one an emitter
+        pos = tuple(float(v) for v in rng.uniform(-2.5, 2.5, 3))
+        rot = tuple(float(v) for v in rng.uniform(-180, 180, 3))
+        size = tuple(float(v) for v in rng.uniform(4.0, 9.0, 3))
+        bx = scenes.make_bxdf(T.BXDF_EMITTER, emissive=(1, 1, 1), intensity=2.0) if i == 0 else scenes.make_bxdf(
+            T.BXDF_DIFFUSE, albedo=tuple(float(v) for v in rng.uniform(0.3, 0.9, 3)))
+        s.add_plane(pos, rot, size, bx)
+    for _ in range(crowd):
+        k = int(rng.integers(0, 3))
+        pos, rot = tuple(float(v) for v in rng.uniform(-2.2, 2.2, 3)), tuple(float(v) for v in rng.uniform(-180, 180, 3))
+        bx = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=tuple(float(v) for v in rng.uniform(0.3, 0.9, 3)))
+        if k == 0:
+            s.add_mesh(cube, pos, rot, tuple(float(v) for v in rng.uniform(0.1, 0.4, 3)), bx)
+        elif k == 1:
+            s.add_sphere(float(rng.uniform(0.08, 0.3)), pos, rot, (1, 1, 1), bx)
+        else:
+            s.add_plane(pos, rot, tuple(float(v) for v in rng.uniform(0.15, 0.5, 3)), bx)
+    scene = s.finalize()
+    assert len(scene) > 32
+    w, h = 96, 64
+    cam = scenes.posed_camera(w, h, position=(0.3, 0.2, 6.0), yaw=-92.0, pitch=-3.0)
+    tracer.upload_scene(scene)
+    bvh = tracer.render(cam, lib.render_params(w, h, 6, 3, 5))
+    rays = tracer.stats().rays_traced
+    assert ", true, 1>" in tracer.kernel_name()
+    brute = tracer.render(cam, lib.render_params(w, h, 6, 3, 5, trace_mode=T.TRACE_BRUTE_FORCE))
+    assert rays == tracer.stats().rays_traced and bvh[1].any()
+    assert np.array_equal(bvh[0], brute[0]) and np.array_equal(bvh[1].view(np.uint32), brute[1].view(np.uint32))
+    n = 600
+    o = rng.uniform(-2.0, 2.0, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32) * rng.uniform(0.2, 3.0, (n, 1)).astype(np.float32)
+    got = tracer.intersect_rays(o, d)
+    exp = oracle_intersect(scene, o, d)
+    hit = exp["hit"].astype(bool)
+    assert hit.sum() > n // 2 and np.array_equal(got["hit"], exp["hit"]) and np.array_equal(got["geom"][hit], exp["geom"][hit])
+    assert np.array_equal(got["t"][hit].view(np.uint32), exp["t"][hit].view(np.uint32))
+    assert np.array_equal(got["tri"][hit], exp["tri"][hit]) and np.array_equal(got["point"][hit].view(np.uint32), exp["point"][hit].view(np.uint32))
+    os.environ["FF_NO_SCAN_PLANES"] = "1"
+    try:
+        tracer.upload_scene(scene)
+        same = tracer.render(cam, lib.render_params(w, h, 6, 3, 5))
+    finally:
+        del os.environ["FF_NO_SCAN_PLANES"]
+    assert np.array_equal(same[1].view(np.uint32), bvh[1].view(np.uint32))
+
+
 def test_crowded_scene_equals_oracle(tracer):
     rng = np.random.default_rng(5)
     scene = fz.rand_scene(rng, small=True, crowd=45)
