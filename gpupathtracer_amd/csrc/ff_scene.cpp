@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <system_error>
 #include <thread>
 
 #include "ff_internal.h"
@@ -242,7 +243,13 @@ struct Builder {
             }
         };
         std::vector<std::thread> pool;
-        for (int w = 1; w < threads; ++w) pool.emplace_back(work);
+        for (int w = 1; w < threads; ++w) {
+            try {
+                pool.emplace_back(work);
+            } catch (const std::system_error&) { // (no more threads to be had: the ones that started, and this one, do the work)
+                break;
+            }
+        }
         work();
         for (std::thread& th : pool) th.join();
         for (size_t q = 0; q < pending.size(); ++q) {
