@@ -430,7 +430,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     }
     FF_HIP(launch_combine(k, st));
     FF_HIP(hipEventRecord(s->ev_end, st));
-    FF_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, 28 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    FF_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (k.timeline) {
         const size_t rows = (size_t)s->num_cus * 2 * (kBlockThreads / 64);
         s->h_timeline_rows.resize(rows * kTimelineBuckets);
@@ -451,7 +451,9 @@ int render_finish(FfState* s)
     unsigned long long c[28];
     std::memcpy(c, s->h_counters, sizeof c);
     std::memcpy(s->raw_counters, c, sizeof c);
-    s->stats.rays_traced = c[0];
+    s->stats.rays_traced = 0;
+    for (int j = 0; j < kRaySlots; ++j) s->stats.rays_traced += s->h_counters[kRaySlotStride * (kRaySlotFirst + j)];
+    s->raw_counters[0] = s->stats.rays_traced;
     s->stats.nodes_visited = c[1];
     s->stats.tris_tested = c[2];
     s->stats.planes_tested = c[3];
@@ -519,7 +521,7 @@ int ff_create(FfState** out_state, int device_id)
         return fail(FF_ERR_HIP, "ff_create: kernel preparation failed: %s (is this a gfx950 device?)", hipGetErrorString(pe));
     }
     if (hipMalloc((void**)&s->d_counters, (size_t)(1 + kQueueCounters) * kQueueStride * sizeof(unsigned)) != hipSuccess || // counters, then the work-queue counters 4 KiB apart
-        hipHostMalloc((void**)&s->h_counters, 32 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&s->h_counters, kCounterWords * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         ff_destroy(s);
         return fail(FF_ERR_HIP, "ff_create: allocating work buffers failed");

@@ -84,6 +84,10 @@ struct KParams {
     unsigned* timeline;
     unsigned timeline_ticks;
 };
+// The ray count of a launch is added up in kRaySlots 64-bit slots of the counter block, kRaySlotStride words apart, from slot
+// kRaySlotFirst on (the first 256 bytes hold the named counters): counters[kRaySlotStride * (kRaySlotFirst + j)].
+constexpr int kRaySlots = 30, kRaySlotFirst = 2, kRaySlotStride = 16;
+constexpr int kCounterWords = 512; // 64-bit words of the counter block (4 KiB; the work-queue counters follow)
 constexpr int kTimelineBuckets = 1024;
 // Work queue: up to kQueueCounters counters, 4 KiB apart so that they sit in different memory channels (atomics on one address
 // are served one after the other, about 10^8 a second for the whole GPU).

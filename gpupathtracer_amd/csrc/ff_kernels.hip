@@ -1602,7 +1602,9 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
 {
     // wave-reduced counters, one atomic per wave and counter
     const unsigned long long rays = wave_sum((unsigned long long)cnt.rays);
-    if (lane == 0 && rays) atomicAdd(&p.counters[0], rays);
+    // (spread over kRaySlots addresses 128 bytes apart: thousands of waves end within microseconds of each other in a short
+    // launch, and atomics on one address are served one after the other, ~10 ns each; the host adds the slots)
+    if (lane == 0 && rays) atomicAdd(&p.counters[kRaySlotStride * (kRaySlotFirst + (blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], rays);
     if (stats) {
         const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
                                  pl = wave_sum((unsigned long long)cnt.planes);
