@@ -382,7 +382,7 @@ def test_launch_timeline_counts_every_ray(monkeypatch):
         us, counts = t.debug_timeline()
         t.set_collect_stats(False)
     assert us == 20 and int(counts.sum()) == rays == inst_rays
-    assert counts[0] > 0 or counts[1] > 0  # the launch starts completing rays within its first 40 us
+    assert counts[:25].any()  # the launch starts completing rays within its first half millisecond
     assert np.array_equal(plain, inst)
     monkeypatch.delenv("FF_DEBUG_TIMELINE_US")
     with lib.Tracer(0) as t:
