@@ -186,26 +186,75 @@ def main():
     # N > 1: every rank renders its strips, rank 0 gathers them behind the C ABI (ff_render_distributed: packed strips, one
     # grouped ncclSend / ncclRecv over RCCL, one scatter kernel).  torch.distributed only carries the 128-byte RCCL id here.
     gather = "none"
+    gather_note = None
+
+    def all_agree(flag):
+        """True iff `flag` holds on every rank (torch's own communicator; every rank must call this the same number of times)."""
+        t = torch.tensor([1 if flag else 0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
     if world > 1 and backend == "nccl":
-        try:
-            box = [lib.dist_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            tracer.dist_init(rank, world, box[0])
-            gather = "native-rccl"
-        except Exception as e:  # noqa: BLE001 - any failure here must not lose the run: fall back to torch's RCCL gather
-            print(f"[bench] rank {rank}: native RCCL gather unavailable ({e}); using torch.distributed.gather", file=sys.stderr, flush=True)
-            gather = "torch-rccl"
-        ok = torch.tensor([1 if gather == "native-rccl" else 0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        gather = "native-rccl" if int(ok.item()) == 1 else "torch-rccl"
+        os.environ.setdefault("FF_DIST_TIMEOUT_S", "120")  # a stuck native gather becomes an error after two minutes, not a hang
+        # Every rank runs every collective below whatever failed locally: a rank that skipped one would leave the others inside it.
+        able = lib.dist_available()
+        uid = None
+        if rank == 0 and able:
+            try:
+                uid = lib.dist_unique_id()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank 0: ff_dist_unique_id failed ({e})", file=sys.stderr, flush=True)
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)  # (None when rank 0 has no id to give)
+        if all_agree(able and box[0] is not None):  # only if ALL ranks can join do any of them enter ff_dist_init, which blocks until all have
+            joined = False
+            try:
+                tracer.dist_init(rank, world, box[0])
+                joined = True
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: ff_dist_init failed ({e})", file=sys.stderr, flush=True)
+            if all_agree(joined):
+                gather = "native-rccl"
+            else:
+                gather, gather_note = "torch-rccl", "ff_dist_init failed on some rank"
+                if joined:
+                    tracer.dist_shutdown()
+        else:
+            gather, gather_note = "torch-rccl", "RCCL could not be loaded by the library on some rank"
     elif world > 1:
         gather = "torch-" + backend
+    full_rgb8 = torch.empty((args.height, args.width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
+    full_rad = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
+    if gather == "native-rccl":
+        # Self-check before anything is timed: one short frame through the native gather against the same frame rendered by rank 0
+        # alone, bit for bit (rows in the wrong place, a wrong part offset or a lost message cannot hide in a rate).  Any error
+        # or difference on any rank sends ALL ranks to torch.distributed's gather, and the JSON line says so.
+        vparams = lib.render_params(args.width, args.height, args.bounces, min(args.spp, 8), args.seed, mode, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+        good = True
+        try:
+            tracer.render_distributed_device(camera, vparams, strip_rows, full_rgb8.data_ptr() if rank == 0 else None,
+                                             full_rad.data_ptr() if rank == 0 else None)
+            if rank == 0:
+                torch.cuda.synchronize()
+                got8, gotr = full_rgb8.clone(), full_rad.clone()
+                tracer.render_device(camera, vparams, full_rgb8.data_ptr(), full_rad.data_ptr())
+                torch.cuda.synchronize()
+                good = bool(torch.equal(got8, full_rgb8)) and bool(torch.equal(gotr.view(torch.int32), full_rad.view(torch.int32)))
+                if not good:
+                    print("[bench] rank 0: the natively gathered frame differs from the frame rendered alone", file=sys.stderr, flush=True)
+        except Exception as e:  # noqa: BLE001
+            good = False
+            print(f"[bench] rank {rank}: native gather failed its self-check ({e})", file=sys.stderr, flush=True)
+        if not all_agree(good):
+            gather, gather_note = "torch-rccl", "the native RCCL gather failed its bitwise self-check against a frame rendered by rank 0 alone"
+            try:
+                tracer.dist_shutdown()
+            except Exception:  # noqa: BLE001
+                pass
     rgb8 = rad = None
     if gather != "native-rccl":
         rgb8 = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.uint8, device=device)
         rad = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.float32, device=device)
-    full_rgb8 = torch.empty((args.height, args.width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
-    full_rad = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
     torch.cuda.synchronize()
 
     def step(cam=None):
@@ -328,7 +377,7 @@ def main():
                             f"{args.bounces} bounces, {args.spp} spp, camera={args.camera}, trace={args.trace_mode}, seed {args.seed}",
                 "scene": args.scene,
                 "rays_per_frame": int(total_rays / args.steps), "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
-                "gather": gather,
+                "gather": gather if gather_note is None else f"{gather} ({gather_note})",
             },
             "roofline": roof,
         }

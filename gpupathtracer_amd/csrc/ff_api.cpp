@@ -152,6 +152,9 @@ int finalize_layout(FfState* s)
         FF_HIP(hipMemcpyAsync(s->d_nodes4 + s->node_capacity, top4.data(), top4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, s->stream));
         FF_HIP(hipStreamSynchronize(s->stream)); // (`top4` goes out of scope)
     }
+    // the axis-aligned walls among the planes every query screens (all planes of a small scene, the leading num_scan of a big one)
+    build_wall_table(s->h_geoms.data(), std::getenv("FF_NO_WALL_TABLE") ? 0 : (s->num_geoms > kChunkGeometries ? s->num_scan : s->num_quads), s->walls);
+    if (s->num_geoms <= kChunkGeometries) add_mesh_boxes(s->h_geoms.data(), s->num_planes, s->num_geoms, s->walls);
     // one entry per visited node above the cursor (inner_step) plus a spare; in big scenes the pending entries of the
     // geometry tree sit below a mesh's own
     s->stack_entries = depth4 + 1 + (s->top_depth > 0 ? s->top_depth + 1 : 0);
@@ -333,6 +336,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.top_lds_first = 0;
     k.top_lds_count = s->top_lds_count;
     k.num_scan = s->num_scan;
+    k.walls = s->walls;
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
@@ -448,7 +452,7 @@ int render_finish(FfState* s)
     FF_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     FF_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
-    unsigned long long c[28];
+    unsigned long long c[32];
     std::memcpy(c, s->h_counters, sizeof c);
     std::memcpy(s->raw_counters, c, sizeof c);
     s->stats.rays_traced = 0;
@@ -744,6 +748,8 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
 
 namespace {
 
+int upload_compiled(FfState* s, const CompiledScene& cs);
+
 int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, const BvhBuildParams& bp)
 {
     CompiledScene cs;
@@ -751,6 +757,14 @@ int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, cons
     int st = compile_scene(host_geometries, n, bp, cs);
     if (st != FF_OK) return st;
     s->build_stats.build_ms = ms_since(t_build);
+    return upload_compiled(s, cs);
+}
+
+// A scene compiled on the host (records, triangle records in leaf order, binary trees) onto the state's device: the copies,
+// then the 4-wide trees derived there.  The same compiled scene may go to several devices (ff_multi_upload_scene).
+int upload_compiled(FfState* s, const CompiledScene& cs)
+{
+    int st = FF_OK;
     FF_HIP(hipSetDevice(s->device));
     free_scene(s);
     s->alloc_countdown = s->debug_fail_alloc;
@@ -818,6 +832,23 @@ int upload_host_built(FfState* s, const FfGeometry* host_geometries, int n, cons
 
 } // namespace
 
+namespace ff {
+
+// ff_upload_scene with a scene the caller compiled (ff_multi_upload_scene: one host build for all devices).  build_ms: what the
+// compilation took, for the state's FfBuildStats.
+int upload_compiled_scene(FfState* s, const CompiledScene& cs, double build_ms)
+{
+    const auto t_call = std::chrono::steady_clock::now();
+    s->build_stats = FfBuildStats();
+    s->build_stats.build_ms = build_ms;
+    const int st = upload_compiled(s, cs);
+    if (st != FF_OK) free_scene(s);
+    s->build_stats.total_ms = ms_since(t_call) + build_ms;
+    return st;
+}
+
+} // namespace ff
+
 extern "C" {
 
 int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
@@ -830,12 +861,27 @@ int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
     int st = compile_scene(host_geometries, n, default_bvh_params(), cs, /*build_bvh=*/false);
     if (st != FF_OK) return st;
     if (cs.geoms.size() != s->h_geoms.size()) return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: %d geometries, the uploaded scene has %zu", n, s->h_geoms.size());
-    for (size_t i = 0; i < cs.geoms.size(); ++i) {
-        GeomRecord& a = cs.geoms[i];
-        const GeomRecord& b = s->h_geoms[i];
-        if (a.type != b.type || a.orig_index != b.orig_index || a.tri_count != b.tri_count || a.tri_first != b.tri_first)
-            return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: geometry %d differs in kind or triangle count from the uploaded one", a.orig_index);
-        a.bvh_root = b.bvh_root;
+    // The compiler orders the planes by the size of their world boxes, which a transform changes: match the new records to the
+    // uploaded ones by the caller's index and keep the UPLOADED order (the mesh slots are parallel to it).  That the leading
+    // planes are the largest is only an optimisation (count_scan_planes); a stale order stays correct.
+    {
+        std::vector<int> where(cs.geoms.size(), -1);
+        for (size_t i = 0; i < cs.geoms.size(); ++i) {
+            const int o = cs.geoms[i].orig_index;
+            if (o >= 0 && (size_t)o < where.size()) where[o] = (int)i;
+        }
+        std::vector<GeomRecord> ordered(cs.geoms.size());
+        for (size_t i = 0; i < s->h_geoms.size(); ++i) {
+            const GeomRecord& b = s->h_geoms[i];
+            const int j = b.orig_index >= 0 && (size_t)b.orig_index < where.size() ? where[b.orig_index] : -1;
+            if (j < 0) return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: geometry %d of the uploaded scene is missing", b.orig_index);
+            GeomRecord a = cs.geoms[j];
+            if (a.type != b.type || a.tri_count != b.tri_count || a.tri_first != b.tri_first)
+                return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: geometry %d differs in kind or triangle count from the uploaded one", a.orig_index);
+            a.bvh_root = b.bvh_root;
+            ordered[i] = a;
+        }
+        cs.geoms.swap(ordered);
     }
     FF_HIP(hipSetDevice(s->device));
     s->h_geoms = cs.geoms;
@@ -1132,6 +1178,7 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.top_lds_first = 0;
     p.top_lds_count = s->top_lds_count;
     p.num_scan = s->num_scan;
+    p.walls = s->walls;
     p.lds_nodes = s->lds_cap; // (the records' LDS shares were laid out for the trace kernel's workgroup; 512 threads leave more room, never less)
     e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);
@@ -1318,11 +1365,11 @@ int ff_debug_timeline(FfState* s, unsigned* out1024, int* bucket_us)
     return FF_OK;
 }
 
-int ff_debug_counters(FfState* s, unsigned long long* out28)
+int ff_debug_counters(FfState* s, unsigned long long* out32)
 {
     clear_error();
-    if (!s || !out28) return fail(FF_ERR_INVALID_ARG, "ff_debug_counters: null argument");
-    std::memcpy(out28, s->raw_counters, sizeof s->raw_counters);
+    if (!s || !out32) return fail(FF_ERR_INVALID_ARG, "ff_debug_counters: null argument");
+    std::memcpy(out32, s->raw_counters, sizeof s->raw_counters);
     return FF_OK;
 }
 

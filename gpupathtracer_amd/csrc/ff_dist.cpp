@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -45,7 +46,11 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (absent from very old libraries: the waits then have a deadline but no early error report / abort)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 Rccl g_rccl;
@@ -73,8 +78,11 @@ int load_rccl()
     FF_SYM(GroupEnd, "ncclGroupEnd")
     FF_SYM(Send, "ncclSend")
     FF_SYM(Recv, "ncclRecv")
+    FF_SYM(AllReduce, "ncclAllReduce")
     FF_SYM(GetErrorString, "ncclGetErrorString")
 #undef FF_SYM
+    *reinterpret_cast<void**>(&r.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
+    *reinterpret_cast<void**>(&r.CommAbort) = dlsym(h, "ncclCommAbort");
     g_rccl = r;
     return FF_OK;
 }
@@ -155,12 +163,61 @@ struct FfDistContext {
     int rank = 0, world = 1;
     bool self_loop = false; // FF_DIST_SELF_LOOP=1: rank 0 also moves its OWN strips through ncclSend/ncclRecv (a one-rank
                             // communicator then exercises the whole transport on a one-GPU box)
+    bool broken = false;    // the transport failed or timed out: the communicator was aborted, ff_dist_init makes a new one
+    double timeout_s = 300.0; // FF_DIST_TIMEOUT_S: longest wait for the other ranks in one frame
+    int* d_status = nullptr;  // [0] this rank's status of the frame, [1] the job's (all-reduce, maximum)
+    int* h_status = nullptr;  // pinned mirror
     unsigned char* d_pack = nullptr; // this rank's packed strips (non-root ranks; rank 0 with self_loop)
     size_t pack_bytes = 0;
     unsigned char* d_gather = nullptr; // rank 0: every part's packed strips, part after part
     size_t gather_bytes = 0;
     double last_gather_ms = 0.0;
 };
+
+namespace {
+
+// The transport is beyond repair (a peer died, a wait ran out): end the communicator's pending work so that this process can
+// report the error and leave instead of sitting in a stream wait for ever.  A fresh process is the retry.
+void abandon_comm(FfDistContext* d)
+{
+    if (d->comm) {
+        if (g_rccl.CommAbort) (void)g_rccl.CommAbort(d->comm);
+        else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
+    }
+    d->comm = nullptr;
+    d->broken = true;
+}
+
+// hipStreamSynchronize with a deadline and an eye on the communicator: returns FF_ERR_COMM (communicator abandoned) when RCCL
+// reports an asynchronous error or the stream has not drained after timeout_s.
+int wait_stream(FfDistContext* d, int device, hipStream_t stream, const char* what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return FF_OK;
+        if (q != hipErrorNotReady) {
+            abandon_comm(d);
+            return fail(FF_ERR_HIP, "rank %d (device %d): %s failed: %s", d->rank, device, what, hipGetErrorString(q));
+        }
+        if (g_rccl.CommGetAsyncError && d->comm) {
+            ncclResult_t ar = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(d->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                abandon_comm(d);
+                return fail(FF_ERR_COMM, "rank %d: RCCL reported an asynchronous error during %s: %s", d->rank, what, g_rccl.GetErrorString(ar));
+            }
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > d->timeout_s) {
+            abandon_comm(d);
+            return fail(FF_ERR_COMM, "rank %d: %s did not complete within %.0f s (FF_DIST_TIMEOUT_S): a peer rank is missing or stuck; communicator aborted",
+                        d->rank, what, d->timeout_s);
+        }
+        if (waited > 200e-6) std::this_thread::sleep_for(std::chrono::microseconds(50)); // (a frame renders for milliseconds: do not burn a core on it)
+    }
+}
+
+} // namespace
 
 namespace ff {
 
@@ -171,6 +228,8 @@ void dist_release(FfState* s)
     if (d->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
     if (d->d_pack) (void)hipFree(d->d_pack);
     if (d->d_gather) (void)hipFree(d->d_gather);
+    if (d->d_status) (void)hipFree(d->d_status);
+    if (d->h_status) (void)hipHostFree(d->h_status);
     delete d;
     s->dist = nullptr;
 }
@@ -220,10 +279,18 @@ int ff_dist_init(FfState* s, int rank, int world_size, const void* id, int bytes
     d->rank = rank;
     d->world = world_size;
     if (const char* e = std::getenv("FF_DIST_SELF_LOOP")) d->self_loop = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FF_DIST_TIMEOUT_S")) d->timeout_s = std::max(1.0, std::atof(e));
+    if (hipMalloc((void**)&d->d_status, 2 * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&d->h_status, 2 * sizeof(int)) != hipSuccess) {
+        if (d->d_status) (void)hipFree(d->d_status);
+        delete d;
+        return fail(FF_ERR_OOM, "ff_dist_init: no memory for the status words");
+    }
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof uid);
     ncclResult_t r = g_rccl.CommInitRank(&d->comm, world_size, uid, rank);
     if (r != ncclSuccess) {
+        (void)hipFree(d->d_status);
+        (void)hipHostFree(d->h_status);
         delete d;
         return fail(FF_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world_size, s->device, g_rccl.GetErrorString(r));
     }
@@ -242,63 +309,108 @@ int ff_dist_shutdown(FfState* s)
 
 int ff_dist_strip_rows(int world_size) { return default_strip_rows(world_size < 1 ? 1 : world_size); }
 
+int ff_dist_available(void)
+{
+    clear_error();
+    return load_rccl();
+}
+
+// One frame over all ranks.  No rank may be left waiting for a message that will never come, so the order is: (1) everything
+// that can fail locally - arguments, buffers, the launches of this rank's strips; (2) the ranks AGREE on a status, one 4-byte
+// all-reduce behind the strips on the same stream, which every rank that got this far posts whatever happened to it in (1);
+// (3) only if all are well, the gather: one message per peer in one group.  A rank that failed in (1) makes the frame an
+// error on EVERY rank (FF_ERR_COMM on the others) and the communicator stays usable.  Every wait on the other ranks has a
+// deadline and watches ncclCommGetAsyncError; when it runs out the communicator is aborted, the call returns FF_ERR_COMM and
+// so does every later one until ff_dist_init has made a new communicator (a fresh process is the retry).
 int ff_render_distributed(FfState* s, const FfCamera* camera, const FfRenderParams* params, int strip_rows, void* rgb8, int rgb8_on_device,
                           float* radiance, int radiance_on_device)
 {
     clear_error();
     const auto t0 = std::chrono::steady_clock::now();
-    int st = check_render_call(s, camera, params, "ff_render_distributed");
-    if (st != FF_OK) return st;
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_render_distributed: state is null");
     FfDistContext* d = s->dist;
     if (!d) return fail(FF_ERR_INVALID_ARG, "ff_render_distributed: call ff_dist_init first");
-    if (strip_rows <= 0) strip_rows = default_strip_rows(d->world);
+    if (d->broken || !d->comm) return fail(FF_ERR_COMM, "ff_render_distributed: the communicator was aborted by an earlier failure; call ff_dist_init again");
     FF_HIP(hipSetDevice(s->device));
-    PackLayout L;
-    L.width = params->width;
-    L.height = params->height;
-    L.strip_rows = strip_rows;
-    L.num_parts = d->world;
     const int rank = d->rank, world = d->world;
-    const int local_rows = ff_strips_local_rows(L.height, strip_rows, rank, world);
     const bool root = rank == 0;
     const bool loop_back = root && d->self_loop;
 
+    // (1) local work
+    PackLayout L;
     RootOutputs out;
     unsigned char* pack = nullptr;
-    if (root) {
-        st = root_outputs(s, params, rgb8, rgb8_on_device, radiance, radiance_on_device, out);
-        if (st == FF_OK) st = ensure_bytes((void**)&d->d_gather, &d->gather_bytes, L.total_bytes() + 16);
-        if (st != FF_OK) return st;
-        pack = d->d_gather; // part 0 sits at offset 0: rendered in place
+    int local = check_render_call(s, camera, params, "ff_render_distributed");
+    if (const char* e = std::getenv("FF_DEBUG_DIST_FAIL_RANK")) // tests: that rank reports an injected local failure
+        if (local == FF_OK && std::atoi(e) == rank) local = fail(FF_ERR_OOM, "injected failure on rank %d (FF_DEBUG_DIST_FAIL_RANK)", rank);
+    if (local == FF_OK) {
+        if (strip_rows <= 0) strip_rows = default_strip_rows(world);
+        L.width = params->width;
+        L.height = params->height;
+        L.strip_rows = strip_rows;
+        L.num_parts = world;
+        if (root) {
+            local = root_outputs(s, params, rgb8, rgb8_on_device, radiance, radiance_on_device, out);
+            if (local == FF_OK) local = ensure_bytes((void**)&d->d_gather, &d->gather_bytes, L.total_bytes() + 16);
+            pack = d->d_gather; // part 0 sits at offset 0: rendered in place
+        }
+        if (local == FF_OK && (!root || loop_back)) {
+            local = ensure_bytes((void**)&d->d_pack, &d->pack_bytes, L.part_bytes(rank) + 16);
+            pack = d->d_pack;
+        }
+        if (local == FF_OK)
+            local = render_enqueue(s, camera, params, strip_rows, rank, world, ff_strips_local_rows(L.height, strip_rows, rank, world), pack + L.rad_bytes(rank),
+                                   reinterpret_cast<float*>(pack));
     }
-    if (!root || loop_back) {
-        st = ensure_bytes((void**)&d->d_pack, &d->pack_bytes, L.part_bytes(rank) + 16);
-        if (st != FF_OK) return st;
-        pack = d->d_pack;
-    }
-    st = render_enqueue(s, camera, params, strip_rows, rank, world, local_rows, pack + L.rad_bytes(rank), reinterpret_cast<float*>(pack));
-    if (st != FF_OK) return st;
 
-    // The gather: one message per peer, all in one group, on the stream the strips were rendered on.
+    // (2) agreement (the error text of a local failure stays this thread's last error)
+    int verdict = local;
+    if (world > 1 || loop_back) {
+        d->h_status[0] = local == FF_OK ? 0 : 1;
+        d->h_status[1] = -1;
+        hipError_t e = hipMemcpyAsync(d->d_status, d->h_status, sizeof(int), hipMemcpyHostToDevice, s->stream);
+        ncclResult_t r = ncclSuccess;
+        if (e == hipSuccess) r = g_rccl.AllReduce(d->d_status, d->d_status + 1, 1, ncclInt32, ncclMax, d->comm, s->stream);
+        if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(d->h_status + 1, d->d_status + 1, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+        if (e != hipSuccess || r != ncclSuccess) {
+            // this rank cannot even post its status: the others will run into their deadline; nothing more to do here
+            abandon_comm(d);
+            return fail(FF_ERR_COMM, "rank %d could not post its frame status: %s", rank, e != hipSuccess ? hipGetErrorString(e) : g_rccl.GetErrorString(r));
+        }
+        const int wst = wait_stream(d, s->device, s->stream, "the ranks' status agreement");
+        if (wst != FF_OK) return wst;
+        if (d->h_status[1] != 0 && local == FF_OK) verdict = FF_ERR_COMM;
+    }
+    if (verdict != FF_OK) {
+        // the frame is off on every rank; what this rank had enqueued has drained (or never started)
+        if (local == FF_OK) {
+            (void)render_finish(s);
+            return fail(FF_ERR_COMM, "ff_render_distributed: another rank failed before the gather (its own call reports why); frame dropped on rank %d", rank);
+        }
+        s->pending = false;
+        return local;
+    }
+
+    // (3) the gather: one message per peer, all in one group, on the stream the strips were rendered on
     const auto t_gather = std::chrono::steady_clock::now();
     if (world > 1 || loop_back) {
-        FF_NCCL(g_rccl.GroupStart());
-        ncclResult_t r = ncclSuccess;
-        if (!root || loop_back) {
-            if (L.part_bytes(rank) > 0) r = g_rccl.Send(pack, L.part_bytes(rank), ncclChar, 0, d->comm, s->stream);
-        }
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess && (!root || loop_back) && L.part_bytes(rank) > 0) r = g_rccl.Send(pack, L.part_bytes(rank), ncclChar, 0, d->comm, s->stream);
         if (root && r == ncclSuccess) {
             for (int p = loop_back ? 0 : 1; p < world && r == ncclSuccess; ++p)
                 if (L.part_bytes(p) > 0) r = g_rccl.Recv(d->d_gather + L.part_offset(p), L.part_bytes(p), ncclChar, p, d->comm, s->stream);
         }
         const ncclResult_t e = g_rccl.GroupEnd();
-        if (r != ncclSuccess || e != ncclSuccess)
-            return fail(FF_ERR_COMM, "framebuffer gather failed on rank %d: %s", rank, g_rccl.GetErrorString(r != ncclSuccess ? r : e));
+        if (r != ncclSuccess || e != ncclSuccess) {
+            abandon_comm(d);
+            return fail(FF_ERR_COMM, "framebuffer gather failed on rank %d: %s; communicator aborted", rank, g_rccl.GetErrorString(r != ncclSuccess ? r : e));
+        }
     }
     if (root) FF_HIP(launch_unpack_strips(d->d_gather, out.rgb8, out.radiance, L.width, L.height, strip_rows, world, s->stream));
+    int st = wait_stream(d, s->device, s->stream, "the framebuffer gather"); // (a rank without rows enqueued no frame but still took part in the gather)
+    if (st != FF_OK) return st;
     st = render_finish(s);
     if (st != FF_OK) return st;
-    FF_HIP(hipStreamSynchronize(s->stream)); // (a rank without rows enqueued no frame but still took part in the gather)
     d->last_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
     if (root) {
         st = copy_root_outputs_to_host(s, params, rgb8, rgb8_on_device, radiance, radiance_on_device, out);
@@ -394,8 +506,25 @@ int ff_multi_upload_scene(FfMulti* m, const FfGeometry* host_geometries, int n)
 {
     clear_error();
     if (!m) return fail(FF_ERR_INVALID_ARG, "ff_multi_upload_scene: handle is null");
+    // The scene is replicated: every GPU traces against all of it.  With the host builder it is compiled ONCE (records, SAH
+    // trees, triangle records: the expensive part, 436 ms for the 983 040-triangle sphere) and the compiled arrays go to every
+    // device (kernel.cu:268-298 uploads once, too).  Device builders run per device: their builds take milliseconds.
+    bool all_host = true;
+    for (FfState* s : m->states) all_host = all_host && s->builder == FF_BUILD_HOST_SAH;
+    if (all_host && m->states.size() > 1) {
+        CompiledScene cs;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int st = compile_scene(host_geometries, n, default_bvh_params(), cs);
+        if (st != FF_OK) return st;
+        const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (size_t i = 0; i < m->states.size(); ++i) {
+            const int ust = upload_compiled_scene(m->states[i], cs, i == 0 ? build_ms : 0.0); // (the build is charged to the first state)
+            if (ust != FF_OK) return ust;
+        }
+        return FF_OK;
+    }
     for (FfState* s : m->states) {
-        const int st = ff_upload_scene(s, host_geometries, n); // the scene is replicated: every GPU traces against all of it
+        const int st = ff_upload_scene(s, host_geometries, n);
         if (st != FF_OK) return st;
     }
     return FF_OK;

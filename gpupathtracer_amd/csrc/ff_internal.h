@@ -94,6 +94,45 @@ struct GeomRecord {
 };
 static_assert(sizeof(GeomRecord) == 16 * 16 + 32, "GeomRecord layout");
 
+// Axis-aligned walls.  A plane whose model matrix maps the unit quad (kernel.cu:18) onto a rectangle parallel to two world axes
+// (rotations by multiples of 90 degrees, any scale and translation: every wall of a box scene) is screened in WORLD space by a
+// wave-uniform loop over this table (scan_records / screen_walls): parameter t = (c - o_k) / d_k of the plane x_k = c, two range
+// checks on the other two coordinates.  The table travels in the kernel arguments (scalar loads, no LDS gathers, no registers
+// per record); hits inside the screening margins and near ties fall back to the per-lane screen of the plane's record, which
+// decides with the exact reference test, so results do not depend on the table.  Built by the host (build_wall_table).
+constexpr int kMaxWalls = 16;
+struct Wall {
+    float c;      // the plane: world coordinate along its normal axis
+    float cu, hu; // centre and half extent along the first of the other two axes (x: y, y: z, z: x)
+    float cv, hv; // ... and along the second (x: z, y: x, z: y)
+    int geom;     // record index of the plane
+    int pad[2];
+};
+static_assert(sizeof(Wall) == 32, "32-byte wall");
+struct WallTable {
+    int count[3];   // walls normal to the world x axis: w[0 .. count[0]), then those normal to y, then to z
+    unsigned mask;  // bit g: plane record g is in the table
+    float margin_s; // S: length scale of the screening margins (world units: the walls' sizes and distances from the origin)
+    float graze;    // a ray with |d_k| < graze * |d| is too close to parallel to a wall normal to k for the fast form
+    int num_boxes;  // small scenes: the padded world boxes of the meshes that have a tree, so that the candidate test of a query
+    int pad;        // reads them through scalar loads as well (box[i] belongs to record box[i].geom)
+    Wall w[kMaxWalls];
+    struct MeshBox {
+        float mn[3];
+        int geom;
+        float mx[3];
+        int pad;
+    } box[32];
+};
+
+// Fills the table from the plane records [0, limit) (processing order; limit <= 32).  A plane qualifies when the three axis
+// columns of its model matrix are parallel to three different world axes to within 2e-7 of their lengths (rotations by multiples
+// of 90 degrees come out of glm's cos/sin that exact), its normal is the unit quad's (0, 0, 1) and its scales differ by at most a
+// factor of 16.  At most kMaxWalls planes, the leading (largest) ones.
+void build_wall_table(const struct GeomRecord* geoms, int limit, WallTable& out);
+// ... and the mesh boxes of a small scene (records [first, n), n <= 32).
+void add_mesh_boxes(const struct GeomRecord* geoms, int first, int n, WallTable& out);
+
 struct CompiledScene {
     std::vector<GeomRecord> geoms;
     std::vector<TriRecord> tris;   // leaf order

@@ -79,6 +79,7 @@ struct KParams {
     // debugging (FF_DEBUG_LDS_FILL=words,pattern): fill that many 4-byte words of dynamic LDS with the pattern before anything is
     // staged, to expose reads of LDS words nobody wrote
     unsigned debug_lds_words, debug_lds_pattern;
+    WallTable walls; // axis-aligned planes, screened by a wave-uniform loop (empty for big scenes beyond their first num_scan records)
     // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
     // wall clock (100 MHz ticks since the first wave started; counters[27] holds that epoch), kTimelineBuckets buckets
     unsigned* timeline;
@@ -110,6 +111,7 @@ struct RayBatchParams {
     int lds_nodes;
     int stack_depth;
     int num_scan;
+    WallTable walls;
 };
 
 // LDS bytes the BVH kernels need for (lds_nodes, stack_depth).

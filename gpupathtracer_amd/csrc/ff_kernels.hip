@@ -63,8 +63,10 @@ struct Counters {
     unsigned no_mesh; // queries that needed no mesh traversal (planes only)
     unsigned stack_overflow; // instrumented launches: pushes beyond the stack's depth (must stay 0: the depth is a bound)
     unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
+    unsigned wall_rounds; // wave-level passes over the table of axis-aligned walls
     unsigned long long t_start, t_inner, t_leaf; // instrumented launches: wave cycles in mesh starts / inner phases / leaf phases
     unsigned long long t_b1, t_b2, t_b3;         // ... and in the three parts of begin_segment (quad boxes / quad screens / mesh boxes)
+    unsigned long long t_l1, t_l2, t_l3;         // ... and of a leaf visit: waiting for the triangle records / the tests / the pop that follows
 };
 
 // Count one wave-level round of a phase: exactly one of the active lanes (the lowest) records it.
@@ -642,7 +644,8 @@ __device__ __forceinline__ void screen_analytic(const LDS& L, int g, const TriRe
     const float ta = num * __builtin_amdgcn_rcpf(dn);                                 // world ray parameter of the plane
     const float Pxa = __builtin_fmaf(ta, ux, ox), Pya = __builtin_fmaf(ta, uy, oy);
     const float omag = fabsf(ox) + fabsf(oy) + fabsf(oz);
-    const float delta = 1.0e-5f * (1.0f + omag);
+    // (an error of the parameter moves the point by that times u / dn: the margin grows with the ray's obliquity to the plane)
+    const float delta = 1.0e-5f * (1.0f + omag) * __builtin_fmaf(fabsf(ux) + fabsf(uy), fabsf(__builtin_amdgcn_rcpf(dn)), 1.0f);
     const float ex = fabsf(Pxa), ey = fabsf(Pya);
     const bool front_sure = ta > 0.0f && fabsf(num) > 1.0e-5f * omag * (fabsf(nx) + fabsf(ny) + fabsf(nz));
     bool hit = ex <= 0.5f - delta && ey <= 0.5f - delta && front_sure && q >= qlim * 1.01f;
@@ -665,6 +668,93 @@ __device__ __forceinline__ void screen_analytic(const LDS& L, int g, const TriRe
     }
 }
 
+// ---- axis-aligned walls (WallTable) ---------------------------------------------------------------------------------------
+//
+// One wall normal to world axis k against the calling lanes' rays, in world space: t = (c - o_k) / d_k through the slab
+// constants of the ray, the hit point's other two coordinates against the rectangle.  (u, v) are the two other axes in the
+// table's order.  Three outcomes per lane: a certain hit (the candidate of the lane if it is clearly the nearest so far), a
+// certain miss, or `slow` gets the wall's bit: the per-lane screen of the plane's record decides, with the exact reference test
+// where it is close (kernel.cu:8-32).  Certain means: by more than `dl` in the rectangle's plane - a multiple of the rounding
+// error of BOTH this form and the reference's object-space arithmetic, which grows with the ray's obliquity to the wall (an
+// error of the parameter moves the point by that times d_u / d_k) - and by more than `tt` in the parameter's sign.  NaNs (an
+// origin beyond 1e8) compare false everywhere and land in `slow`.
+__device__ __forceinline__ void wall_test(const Wall& w, float ixk, float oxk, float ou, float du, float ov, float dv, float dl, float tt, bool steep,
+                                          float wlen, float& best_d, int& best_g, bool& tie, unsigned& slow)
+{
+    const float t = __builtin_fmaf(w.c, ixk, oxk);
+    const float pu = __builtin_fmaf(t, du, ou), pv = __builtin_fmaf(t, dv, ov);
+    const float m = fmaxf(fabsf(pu - w.cu) - w.hu, fabsf(pv - w.cv) - w.hv); // > 0: outside the rectangle by that much
+    const bool hit = m <= -dl && t > tt && steep;
+    const bool miss = m > dl || t < -tt;
+    // Straight-line selects: the lanes of a wave disagree on every one of these cases, and a branch here costs more than
+    // the few instructions it skips.
+    slow |= (!hit && !miss) ? 1u << w.geom : 0u;
+    // offer(): clearly farther than the lane's candidate -> dropped; clearly nearer -> the new candidate; else a near tie
+    const float d = t * wlen;
+    const bool nearer = hit && best_d > __builtin_fmaf(d, 1.0f + kRel, kAbs);
+    const bool farther = d > __builtin_fmaf(best_d, 1.0f + kRel, kAbs);
+    tie = tie || (hit && !nearer && !farther);
+    best_d = nearer ? d : best_d;
+    best_g = nearer ? w.geom : best_g;
+}
+
+// All walls of the table against the calling lanes' rays (wave-uniform loops; the table comes through scalar loads).  Must run
+// on a query that holds nothing yet (begin_segment).  A lane that met a near tie between two walls gives all of them to the
+// per-lane screens, which rank on exact distances.
+template <bool STATS>
+__device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, const WorldSlab& ws, float wlen, Segment& S, unsigned& slow, Counters& cnt)
+{
+    const int nx = W.count[0], ny = nx + W.count[1], nz = ny + W.count[2];
+    if (nz == 0) return;
+    if (STATS) { cnt.planes += (unsigned)nz; probe_round(cnt.wall_rounds); }
+    const float D = 2.0e-5f * ((fabsf(wr.ox) + fabsf(wr.oy)) + (fabsf(wr.oz) + W.margin_s));
+    const float th = 0.05f * D;
+    const float ax = fabsf(wr.dx), ay = fabsf(wr.dy), az = fabsf(wr.dz);
+    const float aix = fabsf(ws.ix), aiy = fabsf(ws.iy), aiz = fabsf(ws.iz);
+    const float gmin = W.graze * wlen;
+    float best_d = kInf;
+    int best_g = -1;
+    bool tie = false;
+    // (the record of the next wall is requested before the current one is tested: a scalar load per iteration would otherwise
+    // sit in front of every test)
+    Wall cur = W.w[0];
+    int i = 0;
+    {
+        const float dl = D * __builtin_fmaf(fmaxf(ay, az), aix, 1.0f), tt = th * aix;
+        const bool steep = ax >= gmin;
+        for (; i < nx; ++i) {
+            const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
+            wall_test(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            cur = nxt;
+        }
+    }
+    {
+        const float dl = D * __builtin_fmaf(fmaxf(az, ax), aiy, 1.0f), tt = th * aiy;
+        const bool steep = ay >= gmin;
+        for (; i < ny; ++i) {
+            const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
+            wall_test(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            cur = nxt;
+        }
+    }
+    {
+        const float dl = D * __builtin_fmaf(fmaxf(ax, ay), aiz, 1.0f), tt = th * aiz;
+        const bool steep = az >= gmin;
+        for (; i < nz; ++i) {
+            const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
+            wall_test(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            cur = nxt;
+        }
+    }
+    if (tie) {
+        slow |= W.mask;
+    } else if (best_g >= 0) {
+        S.pend.dist = best_d;
+        S.pend.geom = best_g;
+        S.pend.rec = -1;
+    }
+}
+
 // Start a closest-hit query: test every plane (fast form) and remember which meshes the ray can reach.
 //
 // Planes are pre-filtered by their world boxes in a wave-uniform loop, then screened per lane WITHOUT the IEEE sqrt/divide
@@ -674,10 +764,10 @@ __device__ __forceinline__ void screen_analytic(const LDS& L, int g, const TriRe
 // Scenes of up to 32 geometries (the reference has 5): every query screens all planes / spheres and collects its candidate meshes
 // in a bit mask (larger scenes walk the geometry tree instead: enter_top / geom_step).
 template <bool STATS, class LDS>
-__device__ __forceinline__ void scan_records(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+__device__ __forceinline__ void scan_records(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                            const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
-    const int prim_end = num_planes, geom_end = num_geoms;
+    const int prim_end = num_planes;
     const float wlen = __builtin_amdgcn_rcpf(inv_length(wr)); // |world direction| (1 for the integrator's rays)
 
     // Stage 1, wave-uniform: which quads can the ray reach at all?  The padded world box of a quad is flat, so for the
@@ -686,7 +776,11 @@ __device__ __forceinline__ void scan_records(const LDS& L, const GeomRecord* __r
     if (STATS) tb0 = __builtin_amdgcn_s_memtime();
     const WorldSlab ws = make_world_slab(wr);
     unsigned quads = 0u;
+    // Stage 0, wave-uniform: the axis-aligned walls in world space (one multiply-add and two range checks each; the walls of a box
+    // scene never reach the per-lane screens below except on their edges)
+    screen_walls<STATS>(W, wr, ws, wlen, S, quads, cnt);
     for (int g = 0; g < prim_end; ++g) {
+        if ((W.mask >> g) & 1u) continue;
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
         if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) quads |= 1u << g;
     }
@@ -703,9 +797,14 @@ __device__ __forceinline__ void scan_records(const LDS& L, const GeomRecord* __r
     // meshes: conservative world-box test against what the planes already found
     S.meshes = 0u;
     const float limit = fminf(S.best.dist, S.pend.dist);
-    for (int g = num_planes; g < geom_end; ++g) {
-        const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
-        if (lds_geom_i4(L, g, 17).x >= 0 && slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, limit)) S.meshes |= 1u << g;
+    {
+        // (the boxes of the meshes that have a tree come with the table: scalar loads, the next one requested before the test)
+        WallTable::MeshBox cur = W.box[0];
+        for (int i = 0; i < W.num_boxes; ++i) {
+            const WallTable::MeshBox nxt = W.box[min(i + 1, 31)];
+            S.meshes |= slab_may_hit(cur.mn[0], cur.mn[1], cur.mn[2], cur.mx[0], cur.mx[1], cur.mx[2], ws, limit) ? 1u << cur.geom : 0u;
+            cur = nxt;
+        }
     }
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
     if (STATS) {
@@ -721,12 +820,14 @@ __device__ __forceinline__ void enter_top(const LDS& L, const Ray& wr, Segment& 
 // of a small scene - world-box pre-filter in a wave-uniform loop, then every lane screens its own candidates - before the walk
 // through the tree starts: the wall the ray ends on bounds that walk from its first node.
 template <bool STATS, class LDS>
-__device__ __forceinline__ void scan_walls(const LDS& L, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+__device__ __forceinline__ void scan_walls(const LDS& L, const WallTable& W, const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
     const float wlen = __builtin_amdgcn_rcpf(inv_length(wr));
     const WorldSlab ws = make_world_slab(wr);
     unsigned prims = 0u;
+    screen_walls<STATS>(W, wr, ws, wlen, S, prims, cnt);
     for (int g = 0; g < L.num_scan; ++g) {
+        if ((W.mask >> g) & 1u) continue;
         const float4 bmin = lds_geom4(L, g, 14), bmax = lds_geom4(L, g, 15);
         if (slab_may_hit(bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z, ws, kInf)) prims |= 1u << g;
     }
@@ -740,7 +841,7 @@ __device__ __forceinline__ void scan_walls(const LDS& L, const TriRecord* __rest
 
 // Start a closest-hit query: empty candidate slots, then the geometry records (small scenes) or the root of the geometry tree.
 template <bool STATS, class LDS>
-__device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+__device__ __forceinline__ void begin_segment(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                               const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
 {
     S.best.dist = kInf; // kernel.cu:131
@@ -757,12 +858,12 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const GeomRecord* __
     if constexpr (LDS::big) {
         // big scenes: the query starts at the root of the tree over the geometries, in world space
         S.meshes = 0u;
-        if (L.num_scan > 0) scan_walls<STATS>(L, tris, wr, S, cnt);
+        if (L.num_scan > 0) scan_walls<STATS>(L, W, tris, wr, S, cnt);
         enter_top(L, wr, S);
         S.cur = 0;
         return;
     }
-    scan_records<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+    scan_records<STATS>(L, W, geoms, num_geoms, num_planes, tris, wr, S, cnt);
 }
 
 // Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
@@ -791,14 +892,9 @@ __device__ __forceinline__ int select_slot(const uint4 q, int c)
 // quarter is read again, the nearest slot becomes the cursor and the entry is rewritten for the rest.  One entry per
 // visited node bounds the stack by the depth of the tree.
 template <class LDS>
-__device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restrict__ nodes4, Segment& S)
+__device__ __forceinline__ void pop_entry(const LDS& L, const uint4* __restrict__ nodes4, Segment& S, int e)
 {
-    if (S.sp == (LDS::big ? S.tl_sp : 0)) {
-        // nothing of the current tree is left; under a mesh of a big scene wait the pending entries of the geometry tree
-        S.cur = LDS::big && S.mesh >= 0 ? kMeshDone : kDone;
-        return;
-    }
-    const int e = stack_pop(L, S.sp - 1);
+    // (`e` is the entry on top of the lane's stack, already read; the caller has checked that the stack is not empty)
     if (e >= 0 && (e & kPackedEntry) != 0) {
         const int node = (e >> 8) & 0x3FFFFF;
         uint4 lk;
@@ -817,6 +913,30 @@ __device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restric
         S.cur = e;
         --S.sp;
     }
+}
+
+template <class LDS>
+__device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restrict__ nodes4, Segment& S)
+{
+    if (S.sp == (LDS::big ? S.tl_sp : 0)) {
+        // nothing of the current tree is left; under a mesh of a big scene wait the pending entries of the geometry tree
+        S.cur = LDS::big && S.mesh >= 0 ? kMeshDone : kDone;
+        return;
+    }
+    pop_entry(L, nodes4, S, stack_pop(L, S.sp - 1));
+}
+
+// The same with the top entry read in advance (`top`: the entry at S.sp - 1 as it was when the step began, undefined for an
+// empty stack): the inner step and the leaf step ask for it together with their node / triangle data, so that a lane that has
+// to pop at the end of the step does not start an LDS round trip of its own there.
+template <class LDS>
+__device__ __forceinline__ void pop_subtree_prefetched(const LDS& L, const uint4* __restrict__ nodes4, Segment& S, int top)
+{
+    if (S.sp == (LDS::big ? S.tl_sp : 0)) {
+        S.cur = LDS::big && S.mesh >= 0 ? kMeshDone : kDone;
+        return;
+    }
+    pop_entry(L, nodes4, S, top);
 }
 
 // Put the lane's cursor on the root of mesh g's tree: object-space ray (kernel.cu:138), slab constants, box planes by the
@@ -928,6 +1048,9 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
 {
     const int rel = S.cur;
     uint4 nx, ny, nz, fx, fy, fz, lk;
+    // (a lane that finds no slot hit pops at the end of this step, and it has pushed nothing by then: the entry it will take is
+    // the one on top of its stack now; slot 0 of an empty stack is read and ignored)
+    const int top = stack_pop(L, max(S.sp - 1, 0));
     if ((unsigned)rel < (unsigned)S.lds_count) {
         const int j = S.lds_first + rel;
         nx = ff_smem[j + S.pnx * L.node_cap];
@@ -984,7 +1107,7 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
         ++S.sp;
     }
     if (k0 != 0xFFFFFFFFu) S.cur = near_link;
-    else pop_subtree(L, nodes4, S);
+    else pop_subtree_prefetched(L, nodes4, S, top);
 }
 
 // One leaf visit: test the leaf's triangles (fast form), then take the next entry off the stack.  On a near tie with the
@@ -1000,9 +1123,19 @@ __device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restr
     const Ray& r = S.osr;
     int k = S.resume > 0 ? S.resume - 1 : 0;
     S.resume = 0;
+    const int top = stack_pop(L, max(S.sp - 1, 0)); // (the leaf step pushes nothing: what it pops at its end is the top entry now)
     if (STATS) probe_round(cnt.leaf_rounds);
+    unsigned long long tl_wait = 0, tl_test = 0, tl0 = 0;
     for (; k < count; ++k) {
+        if (STATS) tl0 = __builtin_amdgcn_s_memtime();
         const float4 A = tp[3 * k], E1 = tp[3 * k + 1], E2 = tp[3 * k + 2];
+        if (STATS) {
+            // (instrumented launches only: the wait for the three loads is made explicit so that it can be told from the arithmetic)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long tl1 = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) tl_wait += tl1 - tl0; // one lane per round keeps the wave's time
+            tl0 = tl1;
+        }
         if (STATS) { cnt.tris += 1; probe_round(cnt.tri_rounds); }
         // kernel.cu:44-75: exact up to the division; every accept/reject comparison is the reference's own
         const float e1x = E1.x, e1y = E1.y, e1z = E1.z;
@@ -1032,13 +1165,27 @@ __device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restr
             }
             if (ok && offer(ta * __builtin_amdgcn_rcpf(S.scale), S.mesh, first + k, S.pend, S.best)) {
                 S.resume = k + 1;
+                if (STATS) tl_test += __builtin_amdgcn_s_memtime() - tl0; // (a near tie: rare, the lane's own count)
                 break;
             }
         }
+        if (STATS) {
+            const unsigned long long tl2 = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) tl_test += tl2 - tl0;
+        }
     }
     refresh_tbound(S);
+    if (STATS) {
+        cnt.t_l1 += tl_wait;
+        cnt.t_l2 += tl_test;
+        tl0 = __builtin_amdgcn_s_memtime();
+    }
     if (S.resume > 0) return;
-    pop_subtree(L, nodes4, S);
+    pop_subtree_prefetched(L, nodes4, S, top);
+    if (STATS) {
+        const unsigned long long tl3 = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) cnt.t_l3 += tl3 - tl0;
+    }
 }
 
 // Settle what is still pending (the common case: the one exact evaluation of the ray, all hitting lanes together) and
@@ -1134,13 +1281,13 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
 
 // A complete closest-hit query for every calling lane (ray-batch kernel).
 template <bool STATS, class LDS>
-__device__ __forceinline__ void closest_hit_deferred(const LDS& L, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+__device__ __forceinline__ void closest_hit_deferred(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                                      const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, const Ray& wr,
                                                      Best& best, Counters& cnt)
 {
     Segment S;
     if (STATS) probe_round(cnt.segment_rounds);
-    begin_segment<STATS>(L, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+    begin_segment<STATS>(L, W, geoms, num_geoms, num_planes, tris, wr, S, cnt);
     traverse_budget<STATS>(L, tris, nodes4, wr, S, cnt, 0, 64, num_planes);
     finish_segment(L, tris, wr, S, best);
     cnt.rays += 1;
@@ -1611,7 +1758,8 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
         const unsigned long long r0 = wave_sum((unsigned long long)cnt.inner_rounds), r1 = wave_sum((unsigned long long)cnt.leaf_rounds),
                                  r2 = wave_sum((unsigned long long)cnt.tri_rounds), r3 = wave_sum((unsigned long long)cnt.plane_rounds),
                                  r4 = wave_sum((unsigned long long)cnt.segment_rounds), r5 = wave_sum((unsigned long long)cnt.no_mesh),
-                                 r6 = wave_sum((unsigned long long)cnt.plane_exact), r7 = wave_sum((unsigned long long)cnt.stack_overflow);
+                                 r6 = wave_sum((unsigned long long)cnt.plane_exact), r7 = wave_sum((unsigned long long)cnt.stack_overflow),
+                                 r8 = wave_sum((unsigned long long)cnt.wall_rounds);
         if (lane == 0) {
             if (n) atomicAdd(&p.counters[1], n);
             if (t) atomicAdd(&p.counters[2], t);
@@ -1624,12 +1772,15 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
             atomicAdd(&p.counters[14], r5);
             atomicAdd(&p.counters[15], r6);
             atomicAdd(&p.counters[26], r7);
+            atomicAdd(&p.counters[31], r8);
         }
         {
             const unsigned long long u0 = wave_sum(cnt.t_start), u1 = wave_sum(cnt.t_inner), u2 = wave_sum(cnt.t_leaf);
             if (lane == 0) { atomicAdd(&p.counters[1 + 15], u0); atomicAdd(&p.counters[2 + 15], u1); atomicAdd(&p.counters[3 + 15], u2); }
             const unsigned long long w0 = wave_sum(cnt.t_b1), w1 = wave_sum(cnt.t_b2), w2 = wave_sum(cnt.t_b3);
             if (lane == 0) { atomicAdd(&p.counters[19], w0); atomicAdd(&p.counters[20], w1); atomicAdd(&p.counters[21], w2); }
+            const unsigned long long l0 = wave_sum(cnt.t_l1), l1 = wave_sum(cnt.t_l2), l2 = wave_sum(cnt.t_l3);
+            if (lane == 0) { atomicAdd(&p.counters[28], l0); atomicAdd(&p.counters[29], l1); atomicAdd(&p.counters[30], l2); }
         }
     }
 }
@@ -1645,10 +1796,13 @@ __device__ __forceinline__ void init_path(Path& P)
 
 // ---- the BVH mega-kernel -------------------------------------------------------------------------------------------------
 //
-// Segment-synchronous: in every round each live lane of the wave runs one complete closest-hit query and then
-// resolves/shades/spawns together with its neighbours.  (A per-lane state machine that let finished lanes wait for a
-// quorum while others kept traversing was measured slower on MI355X: the setup block is too large to run at partial
-// occupancy, see DESIGN.md.)  Latency is hidden by occupancy: 1024 threads per workgroup = 4 waves per SIMD.
+// Time-sliced: every lane is a small state machine (no query / query in flight / query finished).  One iteration of the main
+// loop lets the lanes whose query is finished - or that have none - resolve, shade, fetch work and start their next query
+// TOGETHER (the setup block is large: it only pays at good occupancy), then every lane with a query in flight traverses for
+// one slice of `setup_threshold` inner-node rounds (traverse_budget).  Lanes whose query outlives the slice keep their
+// traversal state in registers and in their LDS stack and simply continue in the next iteration: per-ray traversal cost is
+// heavy-tailed, and run to completion the inner-node phase had 11 % of its lanes busy.  Latency is hidden by occupancy: 1024
+// threads per workgroup = 4 waves per SIMD.
 
 // EXTRAS = false is the instantiation for scenes made of what the reference itself renders (planes and meshes, diffuse
 // and emitting surfaces): the plane/sphere boundary becomes a compile-time "never" and the MIRROR / GLASS branches of the
@@ -1750,7 +1904,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         if (STATS) t3 = __builtin_amdgcn_s_memtime();
         if (setup && active) {
             if (STATS) probe_round(cnt.segment_rounds);
-            begin_segment<STATS>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
+            begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
             cnt.rays += 1;
             inflight = true;
         }
@@ -1839,7 +1993,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     best.dist = kInf; best.geom = -1; best.rec = -1; best.px = best.py = best.pz = 0.f; best.cx = best.cy = 0.f; best.cz = 1.f;
     Counters cnt = {};
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
-    else if (live) closest_hit_deferred<false>(L, p.geoms, p.num_geoms, p.num_planes, p.tris, nodes4, wr, best, cnt);
+    else if (live) closest_hit_deferred<false>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, nodes4, wr, best, cnt);
     if (!live) return;
     FfIntersect out;
     out.m_intersectionPoint.x = 0.f; out.m_intersectionPoint.y = 0.f; out.m_intersectionPoint.z = 0.f;

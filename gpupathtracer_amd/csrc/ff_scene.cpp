@@ -502,6 +502,84 @@ int count_scan_planes(const std::vector<GeomRecord>& geoms, int num_quads)
     return n;
 }
 
+void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out)
+{
+    std::memset(&out, 0, sizeof out);
+    struct Found {
+        int axis;
+        Wall w;
+    };
+    std::vector<Found> found;
+    float scale_s = 0.f, ratio = 1.f;
+    for (int g = 0; g < limit && g < 32 && (int)found.size() < kMaxWalls; ++g) {
+        const GeomRecord& r = geoms[g];
+        if (r.type != FF_GEOM_PLANE) continue;
+        if (!(r.plane_n[0] == 0.f && r.plane_n[1] == 0.f && r.plane_n[2] == 1.f)) continue; // utilities.h:229's unit quad only
+        const float* col[3] = { r.mod_c0, r.mod_c1, r.mod_c2 };
+        int dom[3];
+        float len[3];
+        bool ok = true;
+        for (int j = 0; j < 3 && ok; ++j) {
+            const float a0 = std::fabs(col[j][0]), a1 = std::fabs(col[j][1]), a2 = std::fabs(col[j][2]);
+            dom[j] = a0 >= a1 && a0 >= a2 ? 0 : (a1 >= a2 ? 1 : 2);
+            len[j] = std::sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+            if (!(len[j] > 1e-20f && len[j] < 1e20f)) ok = false;
+            for (int k = 0; k < 3 && ok; ++k)
+                if (k != dom[j] && std::fabs(col[j][k]) > 2.0e-7f * len[j]) ok = false;
+        }
+        if (!ok || dom[0] == dom[1] || dom[0] == dom[2] || dom[1] == dom[2]) continue;
+        const float smax = std::max(len[0], std::max(len[1], len[2])), smin = std::min(len[0], std::min(len[1], len[2]));
+        if (!(smax <= 16.f * smin)) continue;
+        const float* T = r.mod_c3;
+        if (!(std::fabs(T[0]) < 1e8f && std::fabs(T[1]) < 1e8f && std::fabs(T[2]) < 1e8f)) continue;
+        Found f;
+        f.axis = dom[2]; // the world axis the quad's normal (object z) points along
+        const int u = (f.axis + 1) % 3, v = (f.axis + 2) % 3;
+        // half extents along the other two world axes: half the length of the column (object x or y) that points along each
+        const float hu = 0.5f * (dom[0] == u ? len[0] : len[1]), hv = 0.5f * (dom[0] == v ? len[0] : len[1]);
+        std::memset(&f.w, 0, sizeof f.w);
+        f.w.c = T[f.axis];
+        f.w.cu = T[u];
+        f.w.hu = hu;
+        f.w.cv = T[v];
+        f.w.hv = hv;
+        f.w.geom = g;
+        found.push_back(f);
+        ratio = std::max(ratio, smax / smin);
+        scale_s = std::max(scale_s, smax + std::fabs(T[0]) + std::fabs(T[1]) + std::fabs(T[2]));
+    }
+    int n = 0;
+    for (int axis = 0; axis < 3; ++axis)
+        for (const Found& f : found)
+            if (f.axis == axis) {
+                out.w[n++] = f.w;
+                out.count[axis] += 1;
+                out.mask |= 1u << f.w.geom;
+            }
+    // margins: both scale with the anisotropy of the walls (a rounding error of the object-space test along a short axis is that
+    // much larger in world units along a long one)
+    out.margin_s = ratio * scale_s;
+    out.graze = 1.2e-7f * ratio; // kernel.cu:12: |n.d'| > 1e-7 for the normalised object-space direction d'
+    if (ratio > 1.f) {
+        // D = 2e-5 (|o| + S) must cover ratio * (|o| + ...): fold the factor on |o| into S for the scene's extent instead of a
+        // per-ray multiply: origins of interest lie within the scene, |o|_1 <= 3 * scale_s
+        out.margin_s += (ratio - 1.f) * 3.f * scale_s;
+    }
+}
+
+void add_mesh_boxes(const GeomRecord* geoms, int first, int n, WallTable& out)
+{
+    out.num_boxes = 0;
+    for (int g = first; g < n && g < 32; ++g) {
+        const GeomRecord& r = geoms[g];
+        if (r.type != FF_GEOM_TRIANGLEMESH || r.bvh_root < 0) continue;
+        WallTable::MeshBox& b = out.box[out.num_boxes++];
+        for (int k = 0; k < 3; ++k) { b.mn[k] = r.wmin[k]; b.mx[k] = r.wmax[k]; }
+        b.geom = g;
+        b.pad = 0;
+    }
+}
+
 int collapse_geometry_tree(const std::vector<BvhNode>& binary, std::vector<Bvh4Node>& out)
 {
     out.clear();

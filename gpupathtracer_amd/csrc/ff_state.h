@@ -21,6 +21,7 @@ struct FfState {
     ff::TriRecord* d_tris = nullptr;
     ff::TriNormals* d_normals = nullptr; // vertex normals, parallel to d_tris
     ff::BvhNode* d_nodes = nullptr;   // binary trees: what the builders write and refit works on
+    ff::WallTable walls = {};          // the axis-aligned planes among the records every query screens (finalize_layout)
     int num_scan = 0;                  // big scenes: leading plane records kept out of the geometry tree (count_scan_planes)
     ff::Bvh4Node* d_nodes4 = nullptr; // 4-wide trees derived from them (gpu_collapse_mesh): what the trace kernels traverse;
                                       // mesh i's nodes start at its binary slot's index (slots[i].node_first)
@@ -83,7 +84,7 @@ struct FfState {
                                                    // early-leaf quorum (FF_SETUP_THRESHOLD / FF_LEAF_THRESHOLD)
     FfStats stats;
     const char* last_kernel_name = nullptr; // trace kernel instantiation of the last frame (rocprofv3's spelling)
-    unsigned long long raw_counters[28] = {};
+    unsigned long long raw_counters[32] = {};
     // GL interop
     hipGraphicsResource* pbo_resource = nullptr;
     int pbo_width = 0, pbo_height = 0;
@@ -126,5 +127,8 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
 int render_finish(FfState* s);
 
 void dist_release(FfState* s); // ff_dist.cpp: frees s->dist (called by ff_destroy)
+
+// ff_upload_scene for a scene already compiled on the host (ff_api.cpp).
+int upload_compiled_scene(FfState* s, const CompiledScene& cs, double build_ms);
 
 } // namespace ff

@@ -174,6 +174,9 @@ FF_API int ff_deinterleave_strips(FfState* state, const void* src_dev, void* dst
 #define FF_DIST_ID_BYTES 128
 FF_API int ff_dist_unique_id(void* out_id, int bytes);
 FF_API int ff_dist_init(FfState* state, int rank, int world_size, const void* id, int bytes);
+/* FF_OK if the RCCL library can be loaded in this process (what ff_dist_unique_id / ff_dist_init need).  Lets the ranks of a
+ * job agree that all of them can join BEFORE any of them enters ff_dist_init, which blocks until every rank has. */
+FF_API int ff_dist_available(void);
 FF_API int ff_dist_shutdown(FfState* state);
 
 /* Strip height the distributed renderers use when given strip_rows <= 0: 16 rows for up to 2 GPUs, 8 up to 4, else 4. */
@@ -183,7 +186,15 @@ FF_API int ff_dist_strip_rows(int world_size);
  * s % world == rank (ff_render_strips' partition) into one packed buffer and sends it to rank 0 in a single message;
  * rank 0 receives every peer's message into its gather buffer (one grouped RCCL call) and scatters all strips to image
  * order.  On rank 0, rgb8 / radiance receive the full frame, bit-identical to ff_render's (device or host pointers, as
- * there); on other ranks they are ignored.  Synchronous on return on every rank; ff_stats reports this rank's share. */
+ * there); on other ranks they are ignored.  Synchronous on return on every rank; ff_stats reports this rank's share.
+ *
+ * Errors.  No rank is left waiting for a message that cannot come: every rank first does what can fail locally (argument
+ * checks, buffers, the launches of its strips), then the ranks agree on a status (a 4-byte all-reduce), and only a frame that
+ * is well on every rank is gathered.  A local failure returns its own status on the rank it happened on and FF_ERR_COMM on
+ * every other rank; the communicator stays usable.  Waits on other ranks have a deadline (FF_DIST_TIMEOUT_S in the
+ * environment at ff_dist_init, default 300 seconds) and watch ncclCommGetAsyncError: a missing or dead peer ends the call with
+ * FF_ERR_COMM, the communicator is aborted (ncclCommAbort), and every later call returns FF_ERR_COMM until ff_dist_init has
+ * made a new one.  After such an error the process should exit; a fresh process is the retry. */
 FF_API int ff_render_distributed(FfState* state, const FfCamera* camera, const FfRenderParams* params, int strip_rows,
                                  void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device);
 
@@ -252,8 +263,9 @@ FF_API const char* ff_debug_kernel_name(FfState* state);
  * occupancy of that phase; [4..7],[13] wave cycles spent in resolve / shade / acquire / begin / traverse; [14] plane-only queries [15] exact plane
  * tests; [16..18] wave cycles in mesh starts / inner-node phases / leaf phases; [19..21] the three parts of the begin phase; [22] the
  * slowest wave's loop cycles; [23..25] 100 MHz wall clock, complemented / complemented / plain: first lane to find the work
- * queue empty, first wave start, last wave end. */
-FF_API int ff_debug_counters(FfState* state, unsigned long long* out28);
+ * queue empty, first wave start, last wave end; [28..30] wave cycles of the leaf visits spent waiting for the
+ * triangle records / in the triangle tests / in the pop that follows. */
+FF_API int ff_debug_counters(FfState* state, unsigned long long* out32);
 
 /* With FF_DEBUG_TIMELINE_US=<bucket> in the environment at ff_create, instrumented renders also count the rays that complete in
  * each bucket of the (first) launch's wall clock: 1 024 buckets from the start of the first wave, the last one open-ended.

@@ -96,6 +96,20 @@ def test_rccl_transport_on_a_one_rank_communicator(monkeypatch):
             got = t.render_distributed(cam, params, strip_rows)
             assert _same(got, ref), strip_rows
         assert t.stats().rays_traced > 0
+        # A rank that fails before the gather (here: injected) is an error of the frame, not a stuck receive: the ranks agree on a
+        # status first (a 4-byte all-reduce behind the strips), nobody posts the gather, and the communicator stays usable.
+        monkeypatch.setenv("FF_DEBUG_DIST_FAIL_RANK", "0")
+        with pytest.raises(lib.FireflyError) as e:
+            t.render_distributed(cam, params)
+        assert e.value.status == T.FF_ERR_OOM and "injected" in str(e.value)
+        monkeypatch.delenv("FF_DEBUG_DIST_FAIL_RANK")
+        assert _same(t.render_distributed(cam, params, 8), ref)
+        # invalid arguments on a joined rank go through the same agreement
+        bad = lib.render_params(w, h, 0, 3)
+        with pytest.raises(lib.FireflyError) as e:
+            t.render_distributed(cam, bad)
+        assert e.value.status == T.FF_ERR_INVALID_ARG
+        assert _same(t.render_distributed(cam, params), ref)
         t.dist_shutdown()
         with pytest.raises(lib.FireflyError):
             t.render_distributed(cam, params)

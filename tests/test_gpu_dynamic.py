@@ -339,6 +339,42 @@ def test_update_transforms_matches_fresh_upload(builder):
     assert np.array_equal(rgb8, o_rgb8) and same_bits(rad, o_rad)
 
 
+def test_update_transforms_of_walls(tracer):
+    """Translating, rotating and scaling PLANES through ff_update_transforms: the scene compiler orders the planes by the size
+    of their world boxes, which all three change, so the update has to match records by the caller's index, not by position
+    (ADVICE r2).  Every step gives the frame of a fresh upload and of the oracle; the last one turns an axis-aligned wall
+    (screened through the wall table) into an oblique one and back."""
+    scene = scenes.cornell_wahoo_scene()
+    planes = [i for i, s in enumerate(scene._specs) if s[0] == T.GEOM_PLANE]
+    back, floor, ceiling, left, right, light = planes
+    cam = scenes.posed_camera(72, 54, **POSES["default"])
+    inside = scenes.posed_camera(72, 54, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    params = lib.render_params(72, 54, 4, 2, 3, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
+    steps = [
+        # the back wall shrinks below every other wall, the light grows above them: their positions in the sorted records swap
+        [(back, dict(scale=(1.5, 1.5, 1.5))), (light, dict(scale=(6.0, 6.0, 6.0), position=(0.0, 2.45, 0.0)))],
+        # the right wall moves out and tilts, the floor is stretched along one axis only
+        [(right, dict(position=(2.9, 0.2, 0.1), rotation=(10.0, 70.0, 5.0))), (floor, dict(scale=(7.0, 5.0, 3.0)))],
+        # the left wall turns by another quarter (still axis-aligned), the ceiling by 45 degrees about its normal
+        [(left, dict(rotation=(0.0, 270.0, 90.0))), (ceiling, dict(rotation=(90.0, 0.0, 45.0)))],
+        [],  # and back to the scene as uploaded
+    ]
+    tracer.upload_scene(scene)
+    for k, step in enumerate(steps):
+        moved = scene
+        for gi, change in step:
+            moved = _with_mesh(moved, gi, **change)
+        tracer.update_transforms(moved)
+        for c in (cam, inside):
+            rgb8, rad = tracer.render(c, params)
+            with lib.Tracer(0) as fresh:
+                fresh.upload_scene(moved)
+                f_rgb8, f_rad = fresh.render(c, params)
+            assert np.array_equal(rgb8, f_rgb8) and same_bits(rad, f_rad), f"step {k}: differs from a fresh upload"
+            o_rgb8, o_rad = oracle_render(moved, c, params)
+            assert np.array_equal(rgb8, o_rgb8) and same_bits(rad, o_rad), f"step {k}: differs from the oracle"
+
+
 def test_update_errors(tracer):
     scene = scenes.cornell_wahoo_scene()
     gi = _mesh_index(scene, 0)

@@ -192,3 +192,94 @@ def test_edge_scenes_equal_oracle(name):
                     rgb8, rad = t.render(cam, p)
                     assert np.array_equal(rgb8, o_rgb8), (name, shade, builder, mode)
                     assert np.array_equal(rad.view(np.uint32), o_rad.view(np.uint32)), (name, shade, builder, mode)
+
+
+def _wall_rooms(rng):
+    """A room of axis-aligned quads (rotations by multiples of 90 degrees about all three axes, non-uniform scales up to 1:8,
+    off-centre), a small quad just below its ceiling, one oblique quad and a cube: what the wall table (ff_internal.h WallTable)
+    screens in world space, next to what it leaves to the per-lane screens."""
+    quarter = lambda: float(rng.choice([0.0, 90.0, 180.0, 270.0]))
+    c = rng.uniform(-3.0, 3.0, 3)
+    half = rng.uniform(1.0, 4.0, 3)
+    grey = lambda: scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=tuple(float(v) for v in rng.uniform(0.3, 0.9, 3)))
+    s = scenes.Scene()
+    s.add_mesh(scenes.load_mesh("cube"), tuple(float(v) for v in c + rng.uniform(-0.5, 0.5, 3)), (10.0, 20.0, 30.0), (0.7, 0.7, 0.7), grey())
+    walls = []
+    # a plane's quad lies in its object xy plane: rotate it onto each pair of faces, with extra quarter turns about its normal
+    faces = [((0, 0, -1), (0.0, 0.0)), ((0, 0, 1), (0.0, 0.0)), ((0, -1, 0), (90.0, 0.0)), ((0, 1, 0), (90.0, 0.0)), ((-1, 0, 0), (0.0, 90.0)), ((1, 0, 0), (0.0, 90.0))]
+    for (n, (rx, ry)) in faces:
+        if rng.random() < 0.15:
+            continue  # an open side now and then
+        axis = int(np.argmax(np.abs(n)))
+        pos = c.copy()
+        pos[axis] += n[axis] * half[axis]
+        u, v = [a for a in range(3) if a != axis]
+        # world extents 2 * half[u] x 2 * half[v]; which object axis carries which depends on the rotation
+        rz = quarter()
+        ext = {0: (half[0], half[1]), 1: (half[0], half[2]), 2: (half[2], half[1])}[{2: 0, 1: 1, 0: 2}[axis]]
+        sx, sy = (2 * ext[0], 2 * ext[1]) if rz in (0.0, 180.0) else (2 * ext[1], 2 * ext[0])
+        rot = (rx + (180.0 if rng.random() < 0.3 and rx else 0.0), ry + (180.0 if rng.random() < 0.3 and ry else 0.0), rz)
+        s.add_plane(tuple(float(p) for p in pos), rot, (float(sx), float(sy), float(rng.uniform(0.5, 4.0))), grey())
+        walls.append((axis, pos.copy()))
+    top = c.copy()
+    top[1] += half[1] - 0.01
+    s.add_plane(tuple(float(p) for p in top), (90.0, 0.0, quarter()), (float(half[0]), float(half[2]), 1.0),
+                scenes.make_bxdf(T.BXDF_EMITTER, emissive=(1, 1, 1), intensity=2.0))
+    s.add_plane(tuple(float(v) for v in c + rng.uniform(-0.5, 0.5, 3)), (30.0, 45.0, 10.0), (1.5, 2.5, 1.0), grey())
+    return s.finalize(), c, half
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_wall_table_edges_corners_and_grazing_rays(tracer, seed):
+    """Axis-aligned walls are screened in world space by a wave-uniform loop (csrc/ff_kernels.hip screen_walls); everything inside
+    its margins goes to the exact reference test.  Rays aimed at the walls' edges and corners (offsets from 0 to 1e-3 of the
+    room), rays almost parallel to a wall, origins on and next to wall planes and far outside: ff_intersect_rays through the BVH
+    kernel equals the brute-force kernel and the oracle in every field."""
+    from oracle_lib import oracle_intersect
+    rng = np.random.default_rng(4000 + seed)
+    scene, c, half = _wall_rooms(rng)
+    n = 1500
+    o = (c + rng.uniform(-0.95, 0.95, (n, 3)) * half).astype(np.float64)
+    kind = rng.integers(0, 6, n)
+    # targets on edges / corners of the room's box: two or three coordinates on a face
+    tgt = c + rng.uniform(-1.0, 1.0, (n, 3)) * half
+    for i in range(n):
+        on = rng.choice(3, size=2 if kind[i] % 2 == 0 else 3, replace=False)
+        for a in on:
+            tgt[i, a] = c[a] + (1.0 if rng.random() < 0.5 else -1.0) * half[a]
+        tgt[i] += rng.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-5, 1e-4, -1e-3]) * half * rng.uniform(-1, 1, 3)
+    d = tgt - o
+    graze = kind == 4
+    # almost parallel to a wall: one component tiny
+    ax = rng.integers(0, 3, n)
+    d[graze, ax[graze]] = rng.choice([0.0, 1e-9, -1e-8, 1e-7, -1e-6, 1e-5, 1e-4], graze.sum()) * np.abs(d[graze]).max(axis=1)
+    # origins on a wall plane (and a hair off it), and far outside the room
+    onw = kind == 5
+    o[onw, ax[onw]] = (c[ax[onw]] + np.where(rng.random(onw.sum()) < 0.5, 1.0, -1.0) * half[ax[onw]]
+                       + rng.choice([0.0, 1e-6, -1e-6, 1e-4, -1e-4], onw.sum()))
+    far = rng.random(n) < 0.1
+    o[far] = c + rng.uniform(-6.0, 6.0, (far.sum(), 3)) * half
+    d[far] = tgt[far] - o[far]
+    d *= rng.uniform(0.1, 3.0, (n, 1))  # kernel.cu:138 normalises in object space; world directions of any length
+    o32, d32 = o.astype(np.float32), d.astype(np.float32)
+    tracer.upload_scene(scene)
+    bvh = tracer.intersect_rays(o32, d32, T.TRACE_BVH)
+    brute = tracer.intersect_rays(o32, d32, T.TRACE_BRUTE_FORCE)
+    exp = oracle_intersect(scene, o32, d32)
+    hit = exp["hit"].astype(bool)
+    assert 0.3 * n < hit.sum()
+    for got in (bvh, brute):
+        assert np.array_equal(got["hit"], exp["hit"]) and np.array_equal(got["geom"][hit], exp["geom"][hit])
+        assert np.array_equal(got["t"][hit].view(np.uint32), exp["t"][hit].view(np.uint32))
+        assert np.array_equal(got["tri"][hit], exp["tri"][hit])
+        assert np.array_equal(got["point"][hit].view(np.uint32), exp["point"][hit].view(np.uint32))
+        assert np.array_equal(got["normal"][hit].view(np.uint32), exp["normal"][hit].view(np.uint32))
+    # and as frames: a camera inside the room looking into a corner, path mode, against brute force
+    cam = scenes.posed_camera(96, 72, position=tuple(float(v) for v in c + 0.3 * half), yaw=-135.0, pitch=-35.0)
+    p = lib.render_params(96, 72, 8, 4, 11)
+    a = tracer.render(cam, p)
+    rays = tracer.stats().rays_traced
+    p.trace_mode = T.TRACE_BRUTE_FORCE
+    b = tracer.render(cam, p)
+    assert rays == tracer.stats().rays_traced
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))

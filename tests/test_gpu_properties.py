@@ -382,7 +382,8 @@ def test_launch_timeline_counts_every_ray(monkeypatch):
         us, counts = t.debug_timeline()
         t.set_collect_stats(False)
     assert us == 20 and int(counts.sum()) == rays == inst_rays
-    assert counts[:25].any()  # the launch starts completing rays within its first half millisecond
+    # (where in the launch's wall clock the rays complete depends on the box: tools/timeline_probe.py reports it, nothing here
+    # asserts on it - a correctness suite under -x must not depend on the speed of the machine)
     assert np.array_equal(plain, inst)
     monkeypatch.delenv("FF_DEBUG_TIMELINE_US")
     with lib.Tracer(0) as t:

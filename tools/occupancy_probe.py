@@ -60,6 +60,10 @@ tt = c[16] + c[17] + c[18]
 if tt:
     print(f"traverse split: mesh-start {c[16] / tt:.3f}  inner {c[17] / tt:.3f}  leaf {c[18] / tt:.3f}   "
           f"cycles per inner round {c[17] / max(ir, 1):.0f}  per triangle round {c[18] / max(tr, 1):.0f}")
+tl = c[28] + c[29] + c[30]
+if tl:
+    print(f"leaf split: record wait {c[28] / tl:.3f}  triangle tests {c[29] / tl:.3f}  pop {c[30] / tl:.3f}   cycles per triangle round: wait {c[28] / max(tr, 1):.0f}  "
+          f"test {c[29] / max(tr, 1):.0f};  per leaf round: pop {c[30] / max(lr, 1):.0f}")
 tb = c[19] + c[20] + c[21]
 if tb:
     print(f"begin split: quad boxes {c[19] / tb:.3f}  quad screens {c[20] / tb:.3f}  mesh boxes {c[21] / tb:.3f}   cycles per segment round {tb / max(sr, 1):.0f}")
