@@ -65,9 +65,12 @@ def algorithmic_bytes(st, width, rows, spp):
 
 def measured_pmc(args, world, kernel):
     """The committed PMC measurement of the dominant kernel (profiles/*_pmc.json: rocprofv3 --pmc, separate passes,
-    tools/pmc_passes.sh + tools/pmc_to_json.py) taken on exactly this workload and kernel instantiation; the newest one
-    wins; None if there is none."""
-    best = None
+    tools/pmc_passes.sh + tools/pmc_to_json.py) taken on exactly this workload and kernel instantiation AND on the kernel
+    sources of this tree (kernel_source_hash: a counter file from other sources says nothing about this kernel).  Returns
+    (measurement or None, why not)."""
+    from gpupathtracer_amd.provenance import kernel_source_hash
+    here = kernel_source_hash()
+    best, stale = None, None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if not name.endswith("_pmc.json"):
@@ -79,10 +82,15 @@ def measured_pmc(args, world, kernel):
             if (w["width"], w["height"], w["bounces"], w["spp"], w["n_gpus"], w["camera"], w["trace"], w.get("scene", "c2")) == (
                     args.width, args.height, args.bounces, args.spp, world, args.camera, args.trace_mode, args.scene) and \
                     d["kernel"].replace(" ", "") == kernel.replace(" ", ""):
-                best = dict(d, file="profiles/" + name)
+                if d.get("kernel_source_hash") == here:
+                    best = dict(d, file="profiles/" + name)
+                else:
+                    stale = f"profiles/{name} was taken on other kernel sources (hash {d.get('kernel_source_hash', 'none')}, this tree {here})"
         except (OSError, KeyError, ValueError):
             continue
-    return best
+    if best is not None:
+        return best, None
+    return None, stale or "no committed PMC measurement (profiles/*_pmc.json) matches this workload and kernel instantiation"
 
 
 def host_cores():
@@ -336,7 +344,7 @@ def main():
         mean_launch_s = kernel_ms / max(1, launches) / 1e3
         rays_per_launch = rays / max(1, launches)
         algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, args.spp) / max(1, counted.kernel_launches)
-        pmc = measured_pmc(args, world, kernel)
+        pmc, pmc_why_not = measured_pmc(args, world, kernel)
         roof = {
             # What binds this kernel is VALU issue at partial lane occupancy, not HBM: the scene is
             # LDS/L2 resident.  achieved = wave-level VALU instructions per second, from the committed PMC count per ray of
@@ -357,13 +365,12 @@ def main():
                 "traffic": int(traffic), "hbm_GBps": round(traffic / mean_launch_s / 1e9, 2),
                 "hbm_frac": round(traffic / mean_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                 "algorithmic_vs_hbm": round(algo_bytes_launch / max(traffic, 1.0), 1),
-                "pmc_source": pmc["file"],
+                "pmc_source": pmc["file"], "pmc_kernel_source_hash": pmc["kernel_source_hash"],
                 "note": "algorithmic bytes (SURVEY.md section 8d: 24/ray + 112/node visit + 48/triangle test + framebuffer) are served by LDS and L2; "
                         "`traffic` is what reaches HBM (FETCH_SIZE x2 + WRITE_SIZE from the PMC passes, scaled by rays)",
             })
         else:
-            roof.update({"achieved": None, "frac": None, "traffic": None,
-                         "note": "no committed PMC measurement (profiles/*_pmc.json) matches this workload and kernel instantiation"})
+            roof.update({"achieved": None, "frac": None, "traffic": None, "note": "PMC-derived fields withheld: " + pmc_why_not})
         frame_ms.sort()
         out = {
             "metric": f"Mrays/s (path segments = closest-hit queries, device-counted) at {'1080p' if (args.width, args.height) == (1920, 1080) else f'{args.width}x{args.height}'}, "

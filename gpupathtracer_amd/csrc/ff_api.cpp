@@ -30,6 +30,7 @@ void free_scene(FfState* s)
     s->top_count = s->top_depth = 0;
     s->num_scan = 0;
     if (s->d_parent) (void)hipFree(s->d_parent);
+    if (s->d_role) (void)hipFree(s->d_role);
     s->d_nodes4 = nullptr;
     s->num_nodes4 = s->max_depth4 = 0;
     s->scene_block_threads = s->lds_cap = 0;
@@ -38,6 +39,7 @@ void free_scene(FfState* s)
     s->d_normals = nullptr;
     s->d_nodes = nullptr;
     s->d_parent = nullptr;
+    s->d_role = nullptr;
     s->h_geoms.clear();
     s->slots.clear();
     s->node_capacity = 0;
@@ -170,7 +172,23 @@ int finalize_layout(FfState* s)
     s->scene_block_threads = bvh_block_threads(s, s->block_threads);
     // (a tree too deep even for 512 threads still uploads: brute-force rendering works, BVH rendering reports it)
     const int block = s->scene_block_threads > 0 ? s->scene_block_threads : kBlockThreads;
-    const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_entries, block, lds_records(s))) : 0;
+    // LDS holds tree nodes and the lanes' traversal stacks.  A stack level costs 4 bytes x workgroup size = 36 nodes at 1 024
+    // threads, and the deepest levels are hardly ever reached: when the scene's trees would fit LDS whole but for the stacks, the
+    // stacks keep as many levels as are left (at least kMinLdsStack) and the deeper entries go to global memory (stack_push /
+    // stack_pop).  The benchmark scene: 1 202 nodes + 5 of 11 levels instead of 1 040 nodes + 11 levels; a node fetched from
+    // global memory costs a query hundreds of cycles, a spilled stack entry is rare.  Trees that do not fit anyway keep the
+    // whole stack in LDS.
+    constexpr int kMinLdsStack = 4;
+    s->stack_lds_levels = s->stack_entries;
+    if (s->scene_block_threads > 0 && !std::getenv("FF_NO_STACK_SPILL")) {
+        const int want = nodes4 + s->top_count;
+        if (want > max_lds_nodes(s->stack_entries, block, lds_records(s))) {
+            int levels = s->stack_entries;
+            while (levels > kMinLdsStack && max_lds_nodes(levels, block, lds_records(s)) < want) --levels;
+            if (max_lds_nodes(levels, block, lds_records(s)) >= want) s->stack_lds_levels = levels;
+        }
+    }
+    const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_lds_levels, block, lds_records(s))) : 0;
     s->lds_cap = std::min(cap, nodes4 + s->top_count);
     // the geometry tree first (every query of a big scene starts there), the meshes share the rest
     s->top_lds_count = std::min(s->top_count, cap);
@@ -223,7 +241,7 @@ int collapse_slot(FfState* s, size_t gi, bool with_info)
         slot.parents_linked = true;
     }
     Collapse4Info info;
-    st = gpu_collapse_mesh(s->stream, s->scratch, s->d_nodes, slot.node_first, slot.node_count, s->d_parent + slot.node_first, s->d_nodes4, slot.node_first,
+    st = gpu_collapse_mesh(s->stream, s->scratch, s->d_nodes, slot.node_first, slot.node_count, s->d_parent + slot.node_first, s->d_nodes4, slot.node_first, s->d_role + slot.node_first,
                            with_info ? &info : nullptr);
     if (st != FF_OK) return st;
     if (with_info) {
@@ -325,12 +343,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) {
         unsigned long words = 0, pattern = 0;
         if (std::sscanf(e, "%lu,%lx", &words, &pattern) == 2 && prm->trace_mode == FF_TRACE_BVH) {
-            const size_t bytes = bvh_lds_bytes(s->lds_cap, s->stack_entries, block_threads, lds_records(s));
+            const size_t bytes = bvh_lds_bytes(s->lds_cap, s->stack_lds_levels, block_threads, lds_records(s));
             k.debug_lds_words = (unsigned)std::min<size_t>(words, bytes / 4);
             k.debug_lds_pattern = (unsigned)pattern;
         }
     }
-    k.stack_depth = s->stack_entries;
+    k.stack_depth = s->stack_lds_levels;
+    k.stack_spill = nullptr;
     k.lds_nodes = s->lds_cap;
     k.top_first = (int)s->node_capacity;
     k.top_lds_first = 0;
@@ -356,6 +375,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const uint64_t max_useful = ((uint64_t)k.pix_items * (uint64_t)num_blocks + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
+    if (prm->trace_mode == FF_TRACE_BVH && s->stack_lds_levels < s->stack_entries) {
+        // the stack levels that did not get LDS (finalize_layout): one int per level and thread of the launch
+        const int st = ensure_bytes((void**)&s->d_stack_spill, &s->stack_spill_bytes,
+                                    (size_t)(s->stack_entries - s->stack_lds_levels) * (size_t)grid * (size_t)block_threads * sizeof(int));
+        if (st != FF_OK) return st;
+        k.stack_spill = s->d_stack_spill;
+    }
 
     {
         // Work queue (csrc/ff_kernels.hip acquire_pixel): 16 counters in different memory channels, and a wave takes at least
@@ -403,7 +429,18 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && tail_step < tail_n &&
                              (short_frame || ((num_parts > 1 || s->tail_forced) && last_launch_blocks >= s->tail_min_blocks));
     const size_t tail_bytes = (size_t)k.pix_items * (size_t)tail_n * sizeof(float4); // [sample of the block][pixel item]
-    const bool tail_mode = tail_wanted && tail_bytes <= (16ull << 30); // (also keeps slot indices in 31 bits; C5's ranks at eight GPUs need 4.2 GB)
+    // The buffer stays allocated between frames.  Where the tail is this library's own choice (short one-GPU frames: a viewer at
+    // 64 spp) it may take at most 4 GiB and 2 % of the device's memory (1080p at up to 1 024 spp: 2.1 GB; a 64-spp 4K frame would
+    // need 8.5 GB and goes without); where the caller set up a multi-GPU frame or forced it, up to 16 GiB (also keeps slot indices
+    // in 31 bits; C5's ranks at eight GPUs need 4.2 GB).  FfStats::flags tells which way a frame went.
+    const size_t tail_cap = short_frame ? std::min<size_t>(4ull << 30, s->device_mem_bytes / 50) : (16ull << 30);
+    const bool tail_mode = tail_wanted && tail_bytes <= tail_cap;
+    if (!tail_mode && s->d_tail_samples && s->tail_samples_bytes > (256ull << 20)) {
+        // a frame that does not use it gives a large buffer back (the stream has drained: every render call is synchronous)
+        (void)hipFree(s->d_tail_samples);
+        s->d_tail_samples = nullptr;
+        s->tail_samples_bytes = 0;
+    }
     s->pending_flags = (tail_mode ? FF_STATS_TAIL_ITEMS : 0u) | (tail_wanted && !tail_mode ? FF_STATS_TAIL_SKIPPED_TOO_LARGE : 0u);
     if (tail_mode) {
         int tst = ensure_bytes((void**)&s->d_tail_samples, &s->tail_samples_bytes, tail_bytes);
@@ -429,6 +466,10 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             k.tail_first_item = k.pix_items * k.whole_blocks;
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
+        k.div_pix_items = make_fast_div(k.pix_items);
+        k.div_whole_blocks = make_fast_div(k.whole_blocks);
+        k.div_tiles_per_row = make_fast_div((unsigned)k.tiles_per_row);
+        k.div_strip_rows = make_fast_div((unsigned)k.strip_rows);
         if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
         FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st, &s->last_kernel_name));
     }
@@ -455,6 +496,8 @@ int render_finish(FfState* s)
     unsigned long long c[32];
     std::memcpy(c, s->h_counters, sizeof c);
     std::memcpy(s->raw_counters, c, sizeof c);
+    if (c[0] != 0)
+        return fail(FF_ERR_HIP, "the traversal loop guard cut %llu queries short (a malformed or absurdly deep tree): the frame is not valid", c[0]);
     s->stats.rays_traced = 0;
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_traced += s->h_counters[kRaySlotStride * (kRaySlotFirst + j)];
     s->raw_counters[0] = s->stats.rays_traced;
@@ -501,6 +544,7 @@ int ff_create(FfState** out_state, int device_id)
     if (!s) return fail(FF_ERR_OOM, "ff_create: out of host memory");
     s->device = device_id;
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    s->device_mem_bytes = prop.totalGlobalMem;
     if (const char* bt = std::getenv("FF_BLOCK_THREADS")) {
         const int v = std::atoi(bt);
         if (v == 512 || v == 768 || v == 1024) {
@@ -544,6 +588,7 @@ int ff_destroy(FfState* s)
     free_scene(s);
     if (s->d_stage) (void)hipFree(s->d_stage);
     if (s->d_tail_samples) (void)hipFree(s->d_tail_samples);
+    if (s->d_stack_spill) (void)hipFree(s->d_stack_spill);
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_mean) (void)hipFree(s->d_mean);
@@ -657,6 +702,7 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (node_cap + cs.geoms.size() + 1) * sizeof(Bvh4Node))); // (+ the geometry tree of a big scene)
     FF_HIP(scene_alloc(s, (void**)&s->d_parent, (node_cap ? node_cap : 1) * sizeof(int)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_role, node_cap ? node_cap : 1));
     s->node_capacity = node_cap;
     s->slots.assign(cs.geoms.size(), FfState::MeshSlot());
     int node_base = 0;
@@ -781,6 +827,7 @@ int upload_compiled(FfState* s, const CompiledScene& cs)
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, node_bytes));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (cs.nodes.size() + cs.geoms.size() + 1) * sizeof(Bvh4Node))); // (+ the geometry tree of a big scene)
     FF_HIP(scene_alloc(s, (void**)&s->d_parent, (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(int)));
+    FF_HIP(scene_alloc(s, (void**)&s->d_role, cs.nodes.size() ? cs.nodes.size() : 1));
     if (!cs.tris.empty()) FF_HIP(hipMemcpy(s->d_tris, cs.tris.data(), cs.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
     if (!cs.nodes.empty()) FF_HIP(hipMemcpy(s->d_nodes, cs.nodes.data(), cs.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     s->build_stats.copy_ms = ms_since(t_copy);
@@ -1173,20 +1220,36 @@ int ff_intersect_rays(FfState* s, const FfRay* rays, int n, FfIntersect* out, in
     p.geoms = s->d_geoms;
     p.tris = s->d_tris;
     p.nodes4 = s->d_nodes4;
-    p.stack_depth = s->stack_entries;
+    p.stack_depth = s->stack_lds_levels;
+    p.stack_spill = nullptr;
+    if (trace_mode == FF_TRACE_BVH && s->stack_lds_levels < s->stack_entries) {
+        const size_t threads = (size_t)((n + kBlockThreads - 1) / kBlockThreads) * (size_t)kBlockThreads;
+        const int sst = ensure_bytes((void**)&s->d_stack_spill, &s->stack_spill_bytes, (size_t)(s->stack_entries - s->stack_lds_levels) * threads * sizeof(int));
+        if (sst != FF_OK) {
+            (void)hipFree(d_rays);
+            (void)hipFree(d_out);
+            return sst;
+        }
+        p.stack_spill = s->d_stack_spill;
+    }
     p.top_first = (int)s->node_capacity;
     p.top_lds_first = 0;
     p.top_lds_count = s->top_lds_count;
     p.num_scan = s->num_scan;
     p.walls = s->walls;
+    p.guard_hits = s->d_counters;
+    e = hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long), s->stream);
     p.lds_nodes = s->lds_cap; // (the records' LDS shares were laid out for the trace kernel's workgroup; 512 threads leave more room, never less)
-    e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * sizeof(FfRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_ray_batch(p, trace_mode, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    unsigned long long cut = 0;
+    if (e == hipSuccess) e = hipMemcpy(&cut, s->d_counters, sizeof cut, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * sizeof(FfIntersect), hipMemcpyDeviceToHost);
     (void)hipFree(d_rays);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(FF_ERR_HIP, "ff_intersect_rays failed: %s", hipGetErrorString(e));
+    if (cut != 0) return fail(FF_ERR_HIP, "ff_intersect_rays: the traversal loop guard cut %llu queries short (a malformed or absurdly deep tree)", cut);
     return FF_OK;
 }
 

@@ -51,16 +51,18 @@ int gpu_refit_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
                    const int* d_parent, TriRecord* d_tris, TriNormals* d_normals, BvhNode* d_nodes);
 
 // The 4-wide tree the trace kernels traverse, derived from one mesh's binary nodes [node_first, node_first + node_count)
-// (any builder; node numbers grow level by level, root first): every binary node at even depth becomes a 4-wide node whose
-// slots are its grandchildren — or a child itself where that child is a leaf.  4-wide nodes keep the level order, are
-// written from d_nodes4[node4_first] on, and link to each other RELATIVE to node4_first.  d_parent: this mesh's section of
-// the parent array (gpu_link_parents).  With `info` the call synchronises the stream once and returns the node count and
-// the depth of the 4-wide tree; without (after a refit: same topology, new boxes) it is asynchronous.
+// (any builder; node numbers grow level by level, root first).  Which binary nodes become 4-wide nodes and which are absorbed
+// into the one above them (its slots are then their children) minimises the summed surface area of the 4-wide nodes: the
+// dynamic programme of Ylitie et al. 2017 at width 4 (ff_build.hip; trees deeper than 62 levels: every node at even depth).
+// 4-wide nodes keep the binary nodes' order (numbers grow with depth), are written from d_nodes4[node4_first] on, and link to
+// each other RELATIVE to node4_first.  d_parent: this mesh's section of the parent array (gpu_link_parents).  d_role: one byte
+// per binary node of the mesh, written with `info` (after a build: the call synchronises the stream once and returns the node
+// count and the depth of the 4-wide tree) and READ without it (after a refit: same topology, new boxes; asynchronous).
 struct Collapse4Info {
     int node_count = 0; // 4-wide nodes written
     int depth = 0;      // deepest root-to-leaf path in 4-wide nodes
 };
 int gpu_collapse_mesh(hipStream_t stream, BuildScratch& scratch, const BvhNode* d_nodes, int node_first, int node_count, const int* d_parent,
-                      Bvh4Node* d_nodes4, int node4_first, Collapse4Info* info);
+                      Bvh4Node* d_nodes4, int node4_first, unsigned char* d_role, Collapse4Info* info);
 
 } // namespace ff

@@ -309,6 +309,20 @@ int ff_dist_shutdown(FfState* s)
 
 int ff_dist_strip_rows(int world_size) { return default_strip_rows(world_size < 1 ? 1 : world_size); }
 
+// The wire layout of the gather (PackLayout), for callers and tests: the message part `part` sends to rank 0 and where it lands
+// in rank 0's gather buffer.  A part without rows has no message: neither side posts one (the same predicate on both sides).
+long long ff_dist_part_bytes(int width, int height, int strip_rows, int part, int num_parts, long long* out_offset)
+{
+    if (width < 0 || height < 0 || strip_rows < 1 || num_parts < 1 || part < 0 || part >= num_parts) return -1;
+    PackLayout L;
+    L.width = width;
+    L.height = height;
+    L.strip_rows = strip_rows;
+    L.num_parts = num_parts;
+    if (out_offset) *out_offset = (long long)L.part_offset(part);
+    return (long long)L.part_bytes(part);
+}
+
 int ff_dist_available(void)
 {
     clear_error();

@@ -16,6 +16,25 @@ constexpr int kChunkGeometries = 32;      // BVH mode, up to this many geometrie
                                           // and reads the records from global memory
 constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
 
+// Division of a 32-bit unsigned by a launch constant (Granlund & Montgomery 1994): q = (t + ((n - t) >> sh1)) >> sh2 with
+// t = mulhi(n, mul); exact for every n < 2^32 and d >= 1.  The work queue turns an item number into (pixel, block, tile, row,
+// strip) with five divisions by run-time values; the compiler's expansion of one costs about five of these.
+struct FastDiv {
+    unsigned mul, sh1, sh2, d;
+};
+inline FastDiv make_fast_div(unsigned d)
+{
+    FastDiv f;
+    if (d == 0) d = 1;
+    unsigned l = 0;
+    while (l < 32 && (1ull << l) < d) ++l; // ceil(log2 d)
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 1 ? l - 1 : 0;
+    f.d = d;
+    return f;
+}
+
 // Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).
 struct KParams {
     // camera: columns of invView*invProj (kernel.cu:203), position, far plane, screen size as floats (kernel.cu:200-201)
@@ -34,6 +53,7 @@ struct KParams {
     unsigned queue_chunk; // items a wave takes from the work queue per atomic, at least (a few hundred samples of work)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
+    FastDiv div_pix_items, div_whole_blocks, div_tiles_per_row, div_strip_rows; // n / each of them (acquire_pixel)
     // integrator
     // samples are accumulated in blocks of block_spp (a block sums its samples sequentially from 0; the blocks of a pixel
     // are summed in order by the combine kernel), which makes (pixel, block) an independent work item
@@ -58,7 +78,8 @@ struct KParams {
     // LDS node index top_lds_first
     int top_first, top_lds_first, top_lds_count;
     int lds_nodes;   // LDS node slots (which nodes of which mesh fill them: GeomRecord::lds_nodes / lds_first)
-    int stack_depth; // entries per lane in the LDS traversal stack (depth of the deepest 4-wide tree + 1)
+    int stack_depth; // entries per lane in the LDS traversal stack (depth of the deepest 4-wide tree + 1, or fewer with a spill area)
+    int* stack_spill; // the deeper entries of every lane of the launch (global memory, lane-strided; null: the LDS stack holds them all)
     // outputs (local image: local_rows x width)
     float4* blocksums;       // [pix_items][num_blocks] radiance sums of the sample blocks (tile-major pixel order)
     unsigned char* rgb8;     // 3 bytes per local pixel, or null
@@ -75,7 +96,7 @@ struct KParams {
     int tail_samples_in_block; // samples the tail block holds (the frame's last block may be partial)
     unsigned tail_first_item; // queue index of the first tail item of this launch
     float4* tail_samples;    // [block_spp][pix_items] per-sample radiance of the tail block
-    unsigned long long* counters; // [0] rays [1] inner-node visits [2] triangle tests [3] plane tests
+    unsigned long long* counters; // [0] queries cut short by the traversal loop guard (must stay 0) [1] inner-node visits [2] triangle tests [3] plane tests (rays: the slots below)
     // debugging (FF_DEBUG_LDS_FILL=words,pattern): fill that many 4-byte words of dynamic LDS with the pattern before anything is
     // staged, to expose reads of LDS words nobody wrote
     unsigned debug_lds_words, debug_lds_pattern;
@@ -110,8 +131,10 @@ struct RayBatchParams {
     int top_first, top_lds_first, top_lds_count;
     int lds_nodes;
     int stack_depth;
+    int* stack_spill;
     int num_scan;
     WallTable walls;
+    unsigned long long* guard_hits; // += 1 per query the traversal loop guard cut short (must stay 0)
 };
 
 // LDS bytes the BVH kernels need for (lds_nodes, stack_depth).

@@ -64,6 +64,7 @@ struct Counters {
     unsigned stack_overflow; // instrumented launches: pushes beyond the stack's depth (must stay 0: the depth is a bound)
     unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
     unsigned wall_rounds; // wave-level passes over the table of axis-aligned walls
+    unsigned guard_hits;  // ALL launches: queries cut short by the traversal loop guard (must stay 0; the host turns it into an error)
     unsigned long long t_start, t_inner, t_leaf; // instrumented launches: wave cycles in mesh starts / inner phases / leaf phases
     unsigned long long t_b1, t_b2, t_b3;         // ... and in the three parts of begin_segment (quad boxes / quad screens / mesh boxes)
     unsigned long long t_l1, t_l2, t_l3;         // ... and of a leaf visit: waiting for the triangle records / the tests / the pop that follows
@@ -307,7 +308,9 @@ constexpr int kPackedEntry = 0x40000000;                  // stack entry that na
 struct LdsBase {
     int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j
     int stack_base; // uint index of this lane's stack slot 0 (in units of 4 bytes from ff_smem)
-    int stack_depth; // entries per lane
+    int stack_depth; // entries per lane kept in LDS
+    int* spill;      // deeper entries of this lane: entry e >= stack_depth at spill[(e - stack_depth) * spill_stride] (null: none)
+    size_t spill_stride;
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
@@ -333,9 +336,13 @@ struct LdsT : LdsBase {
 template <int BIG = 0>
 __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int block, int tid, int num_quads, const float4* smooth_normals = nullptr,
                                               const GeomRecord* geoms = nullptr, int top_first = 0, int top_lds_first = 0, int top_lds_count = 0,
-                                              int num_scan = 0)
+                                              int num_scan = 0, int* spill = nullptr)
 {
     LdsT<BIG> L;
+    // Stack entries beyond the LDS levels live in global memory, lane-strided over the whole launch (the host trades the deepest,
+    // rarely used stack levels for tree nodes in LDS: finalize_layout)
+    L.spill_stride = (size_t)gridDim.x * (size_t)block;
+    L.spill = spill ? spill + (size_t)blockIdx.x * (size_t)block + (size_t)tid : nullptr;
     L.num_scan = num_scan;
     L.geoms_g = reinterpret_cast<const float4*>(geoms);
     L.top_first = top_first;
@@ -400,9 +407,17 @@ __device__ __forceinline__ int4 lds_geom_i4(const LDS& L, int g, int k)
     return reinterpret_cast<const int4*>(ff_smem)[L.geom_base + g * kGeomVec4 + k];
 }
 template <class LDS>
-__device__ __forceinline__ void stack_push(const LDS& L, int sp, int v) { reinterpret_cast<int*>(ff_smem)[L.stack_base + sp * L.stride] = v; }
+__device__ __forceinline__ void stack_push(const LDS& L, int sp, int v)
+{
+    if (__builtin_expect(sp < L.stack_depth, 1)) reinterpret_cast<int*>(ff_smem)[L.stack_base + sp * L.stride] = v;
+    else L.spill[(size_t)(sp - L.stack_depth) * L.spill_stride] = v;
+}
 template <class LDS>
-__device__ __forceinline__ int stack_pop(const LDS& L, int sp) { return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride]; }
+__device__ __forceinline__ int stack_pop(const LDS& L, int sp)
+{
+    if (__builtin_expect(sp < L.stack_depth, 1)) return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride];
+    return L.spill[(size_t)(sp - L.stack_depth) * L.spill_stride];
+}
 
 // kernel.cu:138 with the geometry record gathered from LDS by a lane-varying index (same arithmetic as object_space_ray).
 template <class LDS>
@@ -926,19 +941,6 @@ __device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restric
     pop_entry(L, nodes4, S, stack_pop(L, S.sp - 1));
 }
 
-// The same with the top entry read in advance (`top`: the entry at S.sp - 1 as it was when the step began, undefined for an
-// empty stack): the inner step and the leaf step ask for it together with their node / triangle data, so that a lane that has
-// to pop at the end of the step does not start an LDS round trip of its own there.
-template <class LDS>
-__device__ __forceinline__ void pop_subtree_prefetched(const LDS& L, const uint4* __restrict__ nodes4, Segment& S, int top)
-{
-    if (S.sp == (LDS::big ? S.tl_sp : 0)) {
-        S.cur = LDS::big && S.mesh >= 0 ? kMeshDone : kDone;
-        return;
-    }
-    pop_entry(L, nodes4, S, top);
-}
-
 // Put the lane's cursor on the root of mesh g's tree: object-space ray (kernel.cu:138), slab constants, box planes by the
 // signs of the direction.
 template <class LDS>
@@ -1048,9 +1050,6 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
 {
     const int rel = S.cur;
     uint4 nx, ny, nz, fx, fy, fz, lk;
-    // (a lane that finds no slot hit pops at the end of this step, and it has pushed nothing by then: the entry it will take is
-    // the one on top of its stack now; slot 0 of an empty stack is read and ignored)
-    const int top = stack_pop(L, max(S.sp - 1, 0));
     if ((unsigned)rel < (unsigned)S.lds_count) {
         const int j = S.lds_first + rel;
         nx = ff_smem[j + S.pnx * L.node_cap];
@@ -1102,12 +1101,12 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
                              (k3 != 0xFFFFFFFFu ? 3u : 2u));
     const int entry = k2 == 0xFFFFFFFFu ? second_link : packed;
     if (k1 != 0xFFFFFFFFu) {
-        if (STATS && S.sp >= L.stack_depth) cnt.stack_overflow += 1;
+        if (STATS && S.sp >= L.stack_depth) cnt.stack_overflow += 1; // (with a spill area: entries that went there)
         stack_push(L, S.sp, entry);
         ++S.sp;
     }
     if (k0 != 0xFFFFFFFFu) S.cur = near_link;
-    else pop_subtree_prefetched(L, nodes4, S, top);
+    else pop_subtree(L, nodes4, S);
 }
 
 // One leaf visit: test the leaf's triangles (fast form), then take the next entry off the stack.  On a near tie with the
@@ -1123,7 +1122,6 @@ __device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restr
     const Ray& r = S.osr;
     int k = S.resume > 0 ? S.resume - 1 : 0;
     S.resume = 0;
-    const int top = stack_pop(L, max(S.sp - 1, 0)); // (the leaf step pushes nothing: what it pops at its end is the top entry now)
     if (STATS) probe_round(cnt.leaf_rounds);
     unsigned long long tl_wait = 0, tl_test = 0, tl0 = 0;
     for (; k < count; ++k) {
@@ -1181,7 +1179,7 @@ __device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restr
         tl0 = __builtin_amdgcn_s_memtime();
     }
     if (S.resume > 0) return;
-    pop_subtree_prefetched(L, nodes4, S, top);
+    pop_subtree(L, nodes4, S);
     if (STATS) {
         const unsigned long long tl3 = __builtin_amdgcn_s_memtime();
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) cnt.t_l3 += tl3 - tl0;
@@ -1277,6 +1275,9 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
         if (rounds >= limit) break;
         if (++guard > kLoopGuard) break; // never reached by a well-formed tree; bounds the loop so no wave can spin forever
     }
+    // The guard is a bound on a hang, not a way to end a query: a lane it cut short holds a truncated closest hit.  Make that
+    // visible in every build (run-to-completion callers: any unfinished lane; time-sliced callers: only the iteration guard).
+    if ((budget <= 0 || guard > kLoopGuard) && !segment_done(S)) cnt.guard_hits += 1;
 }
 
 // A complete closest-hit query for every calling lane (ray-batch kernel).
@@ -1520,6 +1521,12 @@ __device__ __forceinline__ WaveQueue make_wave_queue(const KParams& p)
     return Q;
 }
 
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f)
+{
+    const unsigned t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 // Pull the next traceable pixel for every calling lane.  Two levels: a wave takes a CHUNK of consecutive items from the global
 // counter (one atomic: what its idle lanes ask for, at least queue_chunk items) and deals them to its lanes with no memory
 // traffic; what is left over serves the wave's next requests.  One counter serves about 10^8 atomics a second, each waiting
@@ -1573,16 +1580,17 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                 const unsigned rel = tail ? item - p.tail_first_item : item;
                 unsigned blk, pitem; // tail: blk is the group index
                 if (tail) {
-                    blk = rel / p.pix_items;
+                    blk = fast_div(rel, p.div_pix_items);
                     pitem = rel - blk * p.pix_items;
                 } else {
-                    pitem = rel / p.whole_blocks;
+                    pitem = fast_div(rel, p.div_whole_blocks);
                     blk = rel - pitem * p.whole_blocks;
                 }
                 const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
-                const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
-                const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
-                const int strip = ly / p.strip_rows;
+                const int trow = (int)fast_div((unsigned)tile, p.div_tiles_per_row);
+                const int lx = (tile - trow * p.tiles_per_row) * 8 + (in & 7);
+                const int ly = trow * 8 + (in >> 3);
+                const int strip = (int)fast_div((unsigned)ly, p.div_strip_rows);
                 const int gy = p.y0 + (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
                 const int gx = p.x0 + lx;
                 if (lx < p.local_width && gx < p.xlim && ly < p.local_rows && gy < p.ylim) {
@@ -1752,6 +1760,10 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
     // (spread over kRaySlots addresses 128 bytes apart: thousands of waves end within microseconds of each other in a short
     // launch, and atomics on one address are served one after the other, ~10 ns each; the host adds the slots)
     if (lane == 0 && rays) atomicAdd(&p.counters[kRaySlotStride * (kRaySlotFirst + (blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], rays);
+    if (__ballot(cnt.guard_hits != 0u) != 0ull) { // (never in a healthy launch: no reduction, no atomic)
+        const unsigned long long g = wave_sum((unsigned long long)cnt.guard_hits);
+        if (lane == 0) atomicAdd(&p.counters[0], g);
+    }
     if (stats) {
         const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
                                  pl = wave_sum((unsigned long long)cnt.planes);
@@ -1815,7 +1827,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr,
-                                      p.geoms, p.top_first, p.top_lds_first, p.top_lds_count, BIG ? p.num_scan : 0);
+                                      p.geoms, p.top_first, p.top_lds_first, p.top_lds_count, BIG ? p.num_scan : 0, p.stack_spill);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (p.debug_lds_words != 0u) {
         for (unsigned i = tid; i < p.debug_lds_words; i += BLOCK) reinterpret_cast<unsigned*>(ff_smem)[i] = p.debug_lds_pattern;
@@ -1977,7 +1989,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
 {
     const int tid = threadIdx.x;
     const LdsT<BIG> L = make_lds<BIG>(p.lds_nodes, p.stack_depth, kBlockThreads, tid, p.num_quads, nullptr, p.geoms, p.top_first, p.top_lds_first,
-                                      p.top_lds_count, BIG ? p.num_scan : 0);
+                                      p.top_lds_count, BIG ? p.num_scan : 0, p.stack_spill);
     const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
     if (MODE == FF_TRACE_BVH) stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, kBlockThreads);
     float4* batch = reinterpret_cast<float4*>(ff_smem);
@@ -1994,6 +2006,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     Counters cnt = {};
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, nodes4, wr, best, cnt);
+    if (live && cnt.guard_hits != 0u && p.guard_hits) atomicAdd(p.guard_hits, 1ull);
     if (!live) return;
     FfIntersect out;
     out.m_intersectionPoint.x = 0.f; out.m_intersectionPoint.y = 0.f; out.m_intersectionPoint.z = 0.f;

@@ -15,6 +15,7 @@ struct FfDistContext; // ff_dist.cpp
 struct FfState {
     int device = 0;
     int num_cus = 0;
+    size_t device_mem_bytes = 0; // total global memory of the device (caps the buffers the library allocates on its own initiative)
     hipStream_t stream = nullptr;
     // scene (device)
     ff::GeomRecord* d_geoms = nullptr;
@@ -31,6 +32,9 @@ struct FfState {
     // from index node_capacity on (0 nodes: a small scene)
     int top_count = 0, top_depth = 0, top_lds_count = 0;
     int stack_entries = 1;                // traversal stack entries per lane the BVH kernels need for this scene
+    int stack_lds_levels = 1;             // ... of which this many live in LDS (finalize_layout); the rest in d_stack_spill
+    int* d_stack_spill = nullptr;         // (stack_entries - stack_lds_levels) x launch threads ints
+    size_t stack_spill_bytes = 0;
     int scene_block_threads = 0, lds_cap = 0; // BVH kernel workgroup size and LDS node slots chosen for this scene (finalize_layout)
     bool has_specular = false;
     uint64_t num_tris = 0;
@@ -47,6 +51,7 @@ struct FfState {
     std::vector<MeshSlot> slots;           // parallel to h_geoms (meshes only)
     size_t node_capacity = 0;              // nodes allocated in d_nodes
     int* d_parent = nullptr;               // node_capacity ints (refit)
+    unsigned char* d_role = nullptr;       // node_capacity bytes: which binary nodes are 4-wide nodes (gpu_collapse_mesh keeps it across refits)
     FfTriangle* d_stage = nullptr;         // staging copy of a caller triangle array (device builder / refit)
     size_t stage_bytes = 0;
     ff::BuildScratch scratch;

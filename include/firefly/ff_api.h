@@ -182,6 +182,11 @@ FF_API int ff_dist_shutdown(FfState* state);
 /* Strip height the distributed renderers use when given strip_rows <= 0: 16 rows for up to 2 GPUs, 8 up to 4, else 4. */
 FF_API int ff_dist_strip_rows(int world_size);
 
+/* The gather's wire layout: bytes of the ONE message part `part` sends to rank 0 (its rows as float3 radiance, then as rgb8,
+ * each section padded to 16 bytes; 0 for a part that owns no rows: then no message is posted on either side) and, through
+ * out_offset (may be null), where it lands in rank 0's gather buffer.  -1 for invalid arguments. */
+FF_API long long ff_dist_part_bytes(int width, int height, int strip_rows, int part, int num_parts, long long* out_offset);
+
 /* One frame over all ranks; every rank calls it with the same camera and params.  Each rank renders the strips
  * s % world == rank (ff_render_strips' partition) into one packed buffer and sends it to rank 0 in a single message;
  * rank 0 receives every peer's message into its gather buffer (one grouped RCCL call) and scatters all strips to image

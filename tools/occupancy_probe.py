@@ -62,6 +62,7 @@ if tt:
           f"cycles per inner round {c[17] / max(ir, 1):.0f}  per triangle round {c[18] / max(tr, 1):.0f}")
 tl = c[28] + c[29] + c[30]
 if tl:
+    print(f"stack entries pushed beyond the LDS levels (spilled), per ray: {c[26] / rays:.4f}")
     print(f"leaf split: record wait {c[28] / tl:.3f}  triangle tests {c[29] / tl:.3f}  pop {c[30] / tl:.3f}   cycles per triangle round: wait {c[28] / max(tr, 1):.0f}  "
           f"test {c[29] / max(tr, 1):.0f};  per leaf round: pop {c[30] / max(lr, 1):.0f}")
 tb = c[19] + c[20] + c[21]

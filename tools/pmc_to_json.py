@@ -12,6 +12,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpupathtracer_amd.provenance import KERNEL_SOURCES, kernel_source_hash
+
 
 def main(root, out_path, note=""):
     tot = defaultdict(lambda: defaultdict(float))
@@ -48,6 +51,8 @@ def main(root, out_path, note=""):
         "workload": {"width": int(m.group(1)), "height": int(m.group(2)), "bounces": int(m.group(3)), "spp": int(m.group(4)),
                      "n_gpus": bench["n_gpus"], "camera": m.group(5), "trace": m.group(6), "scene": bench["config"].get("scene", "c2")},
         "kernel": short,
+        # the sources this kernel was built from (bench.py withholds these numbers from a tree whose hash differs)
+        "kernel_source_hash": kernel_source_hash(), "kernel_source_files": ["gpupathtracer_amd/csrc/" + n for n in KERNEL_SOURCES],
         "rays_per_launch": int(rays),
         "kernel_ms_per_launch_profiled": bench["roofline"]["kernel_ms_per_launch"],
         "valu_insts_per_ray": round(per.get("SQ_INSTS_VALU", 0.0) / rays, 4),
