@@ -466,10 +466,6 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             k.tail_first_item = k.pix_items * k.whole_blocks;
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
-        k.div_pix_items = make_fast_div(k.pix_items);
-        k.div_whole_blocks = make_fast_div(k.whole_blocks);
-        k.div_tiles_per_row = make_fast_div((unsigned)k.tiles_per_row);
-        k.div_strip_rows = make_fast_div((unsigned)k.strip_rows);
         if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
         FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st, &s->last_kernel_name));
     }

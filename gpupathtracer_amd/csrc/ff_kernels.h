@@ -16,25 +16,6 @@ constexpr int kChunkGeometries = 32;      // BVH mode, up to this many geometrie
                                           // and reads the records from global memory
 constexpr int kBruteBatchTris = 1024;     // triangles staged per LDS batch in brute-force mode (48 KiB)
 
-// Division of a 32-bit unsigned by a launch constant (Granlund & Montgomery 1994): q = (t + ((n - t) >> sh1)) >> sh2 with
-// t = mulhi(n, mul); exact for every n < 2^32 and d >= 1.  The work queue turns an item number into (pixel, block, tile, row,
-// strip) with five divisions by run-time values; the compiler's expansion of one costs about five of these.
-struct FastDiv {
-    unsigned mul, sh1, sh2, d;
-};
-inline FastDiv make_fast_div(unsigned d)
-{
-    FastDiv f;
-    if (d == 0) d = 1;
-    unsigned l = 0;
-    while (l < 32 && (1ull << l) < d) ++l; // ceil(log2 d)
-    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.sh1 = l < 1 ? l : 1;
-    f.sh2 = l > 1 ? l - 1 : 0;
-    f.d = d;
-    return f;
-}
-
 // Kernel arguments (passed by value; everything here is wave-uniform and lives in SGPRs).
 struct KParams {
     // camera: columns of invView*invProj (kernel.cu:203), position, far plane, screen size as floats (kernel.cu:200-201)
@@ -53,7 +34,6 @@ struct KParams {
     unsigned queue_chunk; // items a wave takes from the work queue per atomic, at least (a few hundred samples of work)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
-    FastDiv div_pix_items, div_whole_blocks, div_tiles_per_row, div_strip_rows; // n / each of them (acquire_pixel)
     // integrator
     // samples are accumulated in blocks of block_spp (a block sums its samples sequentially from 0; the blocks of a pixel
     // are summed in order by the combine kernel), which makes (pixel, block) an independent work item

@@ -64,7 +64,8 @@ struct Counters {
     unsigned stack_overflow; // instrumented launches: pushes beyond the stack's depth (must stay 0: the depth is a bound)
     unsigned plane_exact; // plane tests that fell inside a screening margin and ran the exact reference test
     unsigned wall_rounds; // wave-level passes over the table of axis-aligned walls
-    unsigned guard_hits;  // ALL launches: queries cut short by the traversal loop guard (must stay 0; the host turns it into an error)
+    unsigned long long guard_hits; // ALL launches, wave-uniform (a scalar register pair): lanes whose query the traversal loop guard cut short
+                                   // (must stay 0; the host turns it into an error)
     unsigned long long t_start, t_inner, t_leaf; // instrumented launches: wave cycles in mesh starts / inner phases / leaf phases
     unsigned long long t_b1, t_b2, t_b3;         // ... and in the three parts of begin_segment (quad boxes / quad screens / mesh boxes)
     unsigned long long t_l1, t_l2, t_l3;         // ... and of a leaf visit: waiting for the triangle records / the tests / the pop that follows
@@ -340,7 +341,8 @@ __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int
 {
     LdsT<BIG> L;
     // Stack entries beyond the LDS levels live in global memory, lane-strided over the whole launch (the host trades the deepest,
-    // rarely used stack levels for tree nodes in LDS: finalize_layout)
+    // rarely used stack levels for tree nodes in LDS: finalize_layout).  (Fetching the pointer from the kernel arguments only when
+    // an entry spills, instead of keeping it in registers, was measured: no gain.)
     L.spill_stride = (size_t)gridDim.x * (size_t)block;
     L.spill = spill ? spill + (size_t)blockIdx.x * (size_t)block + (size_t)tid : nullptr;
     L.num_scan = num_scan;
@@ -1277,7 +1279,7 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
     }
     // The guard is a bound on a hang, not a way to end a query: a lane it cut short holds a truncated closest hit.  Make that
     // visible in every build (run-to-completion callers: any unfinished lane; time-sliced callers: only the iteration guard).
-    if ((budget <= 0 || guard > kLoopGuard) && !segment_done(S)) cnt.guard_hits += 1;
+    if (budget <= 0 || guard > kLoopGuard) cnt.guard_hits |= __ballot(!segment_done(S));
 }
 
 // A complete closest-hit query for every calling lane (ray-batch kernel).
@@ -1521,12 +1523,6 @@ __device__ __forceinline__ WaveQueue make_wave_queue(const KParams& p)
     return Q;
 }
 
-__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f)
-{
-    const unsigned t = __umulhi(n, f.mul);
-    return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
-
 // Pull the next traceable pixel for every calling lane.  Two levels: a wave takes a CHUNK of consecutive items from the global
 // counter (one atomic: what its idle lanes ask for, at least queue_chunk items) and deals them to its lanes with no memory
 // traffic; what is left over serves the wave's next requests.  One counter serves about 10^8 atomics a second, each waiting
@@ -1579,18 +1575,20 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                 const bool tail = p.tail_block >= 0 && item >= p.tail_first_item;
                 const unsigned rel = tail ? item - p.tail_first_item : item;
                 unsigned blk, pitem; // tail: blk is the group index
+                // (Five divisions by launch constants per item.  Host-computed magic multipliers - mulhi, two shifts, two adds each -
+                // were measured: C2 -0.6 %, C3 -1.5 %, the 1-spp frame +-0: v_mul_hi_u32 is a quarter-rate instruction and the compiler's
+                // reciprocal-based expansion is not slower.)
                 if (tail) {
-                    blk = fast_div(rel, p.div_pix_items);
+                    blk = rel / p.pix_items;
                     pitem = rel - blk * p.pix_items;
                 } else {
-                    pitem = fast_div(rel, p.div_whole_blocks);
+                    pitem = rel / p.whole_blocks;
                     blk = rel - pitem * p.whole_blocks;
                 }
                 const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
-                const int trow = (int)fast_div((unsigned)tile, p.div_tiles_per_row);
-                const int lx = (tile - trow * p.tiles_per_row) * 8 + (in & 7);
-                const int ly = trow * 8 + (in >> 3);
-                const int strip = (int)fast_div((unsigned)ly, p.div_strip_rows);
+                const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
+                const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
+                const int strip = ly / p.strip_rows;
                 const int gy = p.y0 + (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
                 const int gx = p.x0 + lx;
                 if (lx < p.local_width && gx < p.xlim && ly < p.local_rows && gy < p.ylim) {
@@ -1760,10 +1758,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
     // (spread over kRaySlots addresses 128 bytes apart: thousands of waves end within microseconds of each other in a short
     // launch, and atomics on one address are served one after the other, ~10 ns each; the host adds the slots)
     if (lane == 0 && rays) atomicAdd(&p.counters[kRaySlotStride * (kRaySlotFirst + (blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], rays);
-    if (__ballot(cnt.guard_hits != 0u) != 0ull) { // (never in a healthy launch: no reduction, no atomic)
-        const unsigned long long g = wave_sum((unsigned long long)cnt.guard_hits);
-        if (lane == 0) atomicAdd(&p.counters[0], g);
-    }
+    if (cnt.guard_hits != 0ull && lane == 0) atomicAdd(&p.counters[0], (unsigned long long)__popcll(cnt.guard_hits)); // (never in a healthy launch)
     if (stats) {
         const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
                                  pl = wave_sum((unsigned long long)cnt.planes);
@@ -2006,7 +2001,7 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
     Counters cnt = {};
     if (MODE == FF_TRACE_BRUTE_FORCE) closest_hit_brute<false>(p.geoms, p.num_geoms, p.tris, batch, live, wr, best, cnt);
     else if (live) closest_hit_deferred<false>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, nodes4, wr, best, cnt);
-    if (live && cnt.guard_hits != 0u && p.guard_hits) atomicAdd(p.guard_hits, 1ull);
+    if (live && ((cnt.guard_hits >> (threadIdx.x & 63)) & 1ull) != 0ull && p.guard_hits) atomicAdd(p.guard_hits, 1ull);
     if (!live) return;
     FfIntersect out;
     out.m_intersectionPoint.x = 0.f; out.m_intersectionPoint.y = 0.f; out.m_intersectionPoint.z = 0.f;
