@@ -175,6 +175,21 @@ __device__ __forceinline__ float coherent_load(const float* p)
     return __int_as_float(__hip_atomic_load(reinterpret_cast<int*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+__device__ __forceinline__ void coherent_store_int(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(float* p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// What the bottom-up kernels hand from thread to thread (boxes, costs, links) is written with agent-scope stores and read with
+// agent-scope loads; the hand-over itself is an arrival counter.  Then the only ordering needed is "my stores have completed
+// before my arrival counts" / "my loads start after it": release_arrival() / acquire_arrival().  A __threadfence() would also
+// write back and invalidate the XCD's whole L2 (the L2s of the eight XCDs are not coherent with each other for ordinary
+// accesses), thousands of times per launch: the 983 040-triangle treelet pass took 12 ms with it and 3 ms without.
+__device__ __forceinline__ void release_arrival() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void acquire_arrival() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+__device__ __forceinline__ int arrive(int* counter, int n = 1) { return __hip_atomic_fetch_add(counter, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ int box_slot(int child, int T) { return child >= 0 ? child : (T - 1) + ~child; }
 
 // boxes: (2T - 1) x 6 floats, internal nodes first, then leaves by sorted position.
@@ -191,19 +206,19 @@ __global__ __launch_bounds__(kBuildBlock) void fit_kernel(const FfTriangle* __re
     grow(b, t.m_v1);
     grow(b, t.m_v2);
     float* mine = boxes + (size_t)((T - 1) + j) * 6;
-    for (int k = 0; k < 3; ++k) { mine[k] = b.mn[k]; mine[3 + k] = b.mx[k]; }
+    for (int k = 0; k < 3; ++k) { coherent_store(mine + k, b.mn[k]); coherent_store(mine + 3 + k, b.mx[k]); }
     int cur = leaf_parent[j];
     for (int guard = 0; guard < 4096; ++guard) { // a path to the root is at most 64 + 31 links long
-        __threadfence(); // publish the box written above before announcing it
-        const int earlier = atomicAdd(&arrivals[cur], 1);
+        release_arrival(); // the box written above is out before it is announced
+        const int earlier = arrive(&arrivals[cur]);
         if (earlier == 0) return; // the sibling subtree is not finished: its last thread completes this node
-        __threadfence(); // see the sibling's box
+        acquire_arrival();
         const float* lb = boxes + (size_t)box_slot(left[cur], T) * 6;
         const float* rb = boxes + (size_t)box_slot(right[cur], T) * 6;
         float* nb = boxes + (size_t)cur * 6;
         for (int k = 0; k < 3; ++k) {
-            nb[k] = fminf(coherent_load(lb + k), coherent_load(rb + k));
-            nb[3 + k] = fmaxf(coherent_load(lb + 3 + k), coherent_load(rb + 3 + k));
+            coherent_store(nb + k, fminf(coherent_load(lb + k), coherent_load(rb + k)));
+            coherent_store(nb + 3 + k, fmaxf(coherent_load(lb + 3 + k), coherent_load(rb + 3 + k)));
         }
         if (cur == 0) return;
         cur = node_parent[cur];
@@ -390,8 +405,10 @@ __global__ __launch_bounds__(kBuildBlock) void treelet_kernel(int T, int* left, 
     float* copt = s_copt[wave];
     unsigned long long* best = s_best[wave];
     unsigned char* popt = s_popt[wave];
+    // (LDS operations of ONE wave are carried out in the order they were issued: what the lanes of this wave exchange through LDS
+    // needs the compiler to keep that order - a wavefront-scope fence and a scheduling barrier - and no wait on the memory system)
     auto wave_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -399,17 +416,20 @@ __global__ __launch_bounds__(kBuildBlock) void treelet_kernel(int T, int* left, 
     bool alive = j < T;
     int cur = -1;
     if (alive) {
-        cost[(T - 1) + j] = kSahTri * box_half_area6(boxes + (size_t)((T - 1) + j) * 6);
+        coherent_store(&cost[(T - 1) + j], kSahTri * box_half_area6(boxes + (size_t)((T - 1) + j) * 6));
         cur = leaf_parent[j];
     }
     for (int guard = 0; guard < 4096; ++guard) {
         int owned = -1;
         if (alive) {
-            __threadfence();
-            if (atomicAdd(&arrivals[cur], 1) == 0) alive = false; // the sibling subtree is not finished: its last thread goes on
+            // Everything this thread (or its wave) wrote for the subtree below went out with agent-scope stores: waiting for them to
+            // complete is all the release the arrival needs, and the reads on the other side are agent-scope loads.  (A full
+            // __threadfence writes back and invalidates the XCD's whole L2 on this chip: the climb does thousands of them.)
+            release_arrival();
+            if (arrive(&arrivals[cur]) == 0) alive = false; // the sibling subtree is not finished
             else owned = cur;
         }
-        __threadfence();
+        acquire_arrival();
         // small subtrees: their owner computes the cost alone; treelet roots wait for the wave
         bool wants_wave = false;
         if (owned >= 0) {
@@ -419,7 +439,7 @@ __global__ __launch_bounds__(kBuildBlock) void treelet_kernel(int T, int* left, 
                 const int l = coherent_load_int(&left[owned]), r = coherent_load_int(&right[owned]);
                 float bb[6];
                 for (int q = 0; q < 6; ++q) bb[q] = coherent_load(boxes + (size_t)owned * 6 + q);
-                cost[owned] = kSahNode * box_half_area6(bb) + coherent_load(&cost[box_slot(l, T)]) + coherent_load(&cost[box_slot(r, T)]);
+                coherent_store(&cost[owned], kSahNode * box_half_area6(bb) + coherent_load(&cost[box_slot(l, T)]) + coherent_load(&cost[box_slot(r, T)]));
             }
         }
         unsigned long long waiting = __ballot(wants_wave);
@@ -566,23 +586,22 @@ __global__ __launch_bounds__(kBuildBlock) void treelet_kernel(int T, int* left, 
                     wave_sync();
                     if (lane < kTreeletLeaves - 1) {
                         const int s = plan[lane * 4], n = plan[lane * 4 + 1], c0 = plan[lane * 4 + 2], c1 = plan[lane * 4 + 3];
-                        left[n] = c0;
-                        right[n] = c1;
-                        if (c0 >= 0) node_parent[c0] = n; else leaf_parent[~c0] = n;
-                        if (c1 >= 0) node_parent[c1] = n; else leaf_parent[~c1] = n;
+                        coherent_store_int(&left[n], c0);
+                        coherent_store_int(&right[n], c1);
+                        coherent_store_int(c0 >= 0 ? &node_parent[c0] : &leaf_parent[~c0], n);
+                        coherent_store_int(c1 >= 0 ? &node_parent[c1] : &leaf_parent[~c1], n);
                         float bb[6];
                         int sz;
                         subset_box(s, bb, sz);
                         float* nb = boxes + (size_t)n * 6;
-                        for (int q = 0; q < 6; ++q) nb[q] = bb[q];
-                        sizes[n] = sz;
-                        cost[n] = copt[s];
+                        for (int q = 0; q < 6; ++q) coherent_store(nb + q, bb[q]);
+                        coherent_store_int(&sizes[n], sz);
+                        coherent_store(&cost[n], copt[s]);
                     }
                 }
                 wave_sync();
             }
-            if (lane == 0) cost[root] = total;
-            __threadfence();
+            if (lane == 0) coherent_store(&cost[root], total);
         }
         // owners climb
         if (owned >= 0) {
@@ -783,14 +802,18 @@ __global__ __launch_bounds__(kBuildBlock) void refit_kernel(const FfTriangle* __
     BvhNode* nd = nodes + n;
     const int l = nd->left, r = nd->right;
     int leaves = 0;
-    if (l < 0) { leaf_box(src, tris, l, pad, nd->lmin, nd->lmax); ++leaves; }
-    if (r < 0) { leaf_box(src, tris, r, pad, nd->rmin, nd->rmax); ++leaves; }
+    {
+        // the boxes of its leaf children (agent-scope stores: a thread on another XCD reads them when it completes this node)
+        float mn[3], mx[3];
+        if (l < 0) { leaf_box(src, tris, l, pad, mn, mx); for (int k = 0; k < 3; ++k) { coherent_store(nd->lmin + k, mn[k]); coherent_store(nd->lmax + k, mx[k]); } ++leaves; }
+        if (r < 0) { leaf_box(src, tris, r, pad, mn, mx); for (int k = 0; k < 3; ++k) { coherent_store(nd->rmin + k, mn[k]); coherent_store(nd->rmax + k, mx[k]); } ++leaves; }
+    }
     if (leaves == 0) return; // both boxes come from below
-    __threadfence();
-    if (atomicAdd(&arrivals[i], leaves) + leaves < 2) return;
+    release_arrival();
+    if (arrive(&arrivals[i], leaves) + leaves < 2) return;
     for (int guard = 0; guard < 4096; ++guard) {
         // node n is complete: both of its child boxes are final
-        __threadfence();
+        acquire_arrival();
         const int p = parent[n - node_first];
         if (p < 0) return; // the root
         const float* a = reinterpret_cast<const float*>(nodes + n);
@@ -804,9 +827,9 @@ __global__ __launch_bounds__(kBuildBlock) void refit_kernel(const FfTriangle* __
         BvhNode* pd = nodes + pn;
         float* dmn = side == 0 ? pd->lmin : pd->rmin;
         float* dmx = side == 0 ? pd->lmax : pd->rmax;
-        for (int k = 0; k < 3; ++k) { dmn[k] = mn[k]; dmx[k] = mx[k]; }
-        __threadfence();
-        if (atomicAdd(&arrivals[pn - node_first], 1) + 1 < 2) return;
+        for (int k = 0; k < 3; ++k) { coherent_store(dmn + k, mn[k]); coherent_store(dmx + k, mx[k]); }
+        release_arrival();
+        if (arrive(&arrivals[pn - node_first]) + 1 < 2) return;
         n = pn;
     }
 }
@@ -892,16 +915,19 @@ __global__ __launch_bounds__(kBuildBlock) void collapse_cost_kernel(const BvhNod
                 d |= ((d >> ((b - 2) * 5)) & 31u) << ((b - 1) * 5);
             }
         }
-        cost[n] = make_float4(c[1], c[2], c[3], c[4]);
-        decision[n] = d;
+        {
+            float* out = reinterpret_cast<float*>(&cost[n]);
+            for (int b = 0; b < 4; ++b) coherent_store(out + b, c[b + 1]);
+        }
+        decision[n] = d; // (read by the NEXT kernel only)
         const int p = parent[n];
         if (p < 0) return;
         const int pn = (p >> 1) - node_first;
         const BvhNode& pd = nodes[node_first + pn];
         const int need = (pd.left >= 0 ? 1 : 0) + (pd.right >= 0 ? 1 : 0);
-        __threadfence();
-        if (atomicAdd(&arrivals[pn], 1) + 1 < need) return;
-        __threadfence();
+        release_arrival();
+        if (arrive(&arrivals[pn]) + 1 < need) return;
+        acquire_arrival();
         n = pn;
     }
 }
@@ -1200,9 +1226,9 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
             nxt = t;
         }
     }
-    // Treelet restructuring passes (FF_TREELET_PASSES, default 2 for the LBVH and 1 for PLOC; 0: none), then every node's
+    // Treelet restructuring passes (FF_TREELET_PASSES; default 2 for the LBVH, none for PLOC), then every node's
     // triangle range and every leaf's place in the leaf order from the final topology.
-    int passes = ploc ? 1 : 2;
+    int passes = ploc ? 0 : 2; // (on PLOC trees a pass buys 1 % on the 5 000-triangle meshes and LOSES 4 % on the regular 983 040-triangle sphere)
     if (const char* e = std::getenv("FF_TREELET_PASSES")) passes = std::max(0, std::min(8, std::atoi(e)));
     if (passes > 0 || ploc) {
         if (!ploc) sizes_from_ranges_kernel<<<node_grid, kBuildBlock, 0, stream>>>(T, b.first, b.last, b.sizes);

@@ -703,8 +703,9 @@ __device__ __forceinline__ void wall_test(const Wall& w, float ixk, float oxk, f
     const float m = fmaxf(fabsf(pu - w.cu) - w.hu, fabsf(pv - w.cv) - w.hv); // > 0: outside the rectangle by that much
     const bool hit = m <= -dl && t > tt && steep;
     const bool miss = m > dl || t < -tt;
-    // Straight-line selects: the lanes of a wave disagree on every one of these cases, and a branch here costs more than
-    // the few instructions it skips.
+    // Straight-line selects throughout.  (The two rare cases - a lane inside a margin, a second certain hit that is not clearly
+    // nearer - behind wave-uniform branches instead: C2 -3 %, the default camera -4 %.  A branch costs this loop more than the
+    // five vector instructions it skips.)
     slow |= (!hit && !miss) ? 1u << w.geom : 0u;
     // offer(): clearly farther than the lane's candidate -> dropped; clearly nearer -> the new candidate; else a near tie
     const float d = t * wlen;

@@ -205,6 +205,40 @@ def test_device_built_tree_structure(lbvh_tracer, mesh):
     assert np.array_equal(tris[key].view(np.uint8), htris[hkey].view(np.uint8))
 
 
+@pytest.mark.parametrize("builder", [T.BUILD_HOST_SAH, T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC], ids=["host_tree", "lbvh_tree", "ploc_tree"])
+def test_collapse_rule_and_treelet_passes_change_the_tree_not_the_frame(monkeypatch, builder):
+    """The 4-wide collapse that minimises the summed node area (csrc/ff_build.hip) against the fixed rule of rounds 1-2
+    (FF_COLLAPSE_PARITY=1), and the device builders with and without their treelet restructuring passes (FF_TREELET_PASSES):
+    every variant is a well-formed tree, renders the same bits, and the better tree is the smaller / cheaper one."""
+    scene = scenes.cornell_wahoo_scene()
+    cam = scenes.posed_camera(96, 72, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    params = lib.render_params(96, 72, 6, 4, 9)
+    out = {}
+    variants = [("optimal", {}), ("parity", {"FF_COLLAPSE_PARITY": "1"})]
+    if builder != T.BUILD_HOST_SAH:
+        variants += [("no_treelets", {"FF_TREELET_PASSES": "0"}), ("three_passes", {"FF_TREELET_PASSES": "3"})]
+    for name, env in variants:
+        for k in ("FF_COLLAPSE_PARITY", "FF_TREELET_PASSES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with lib.Tracer(0) as t:
+            t.set_builder(builder)
+            t.upload_scene(scene)
+            check_trees(t, len(scene))
+            t.set_collect_stats(True)
+            rgb8, rad = t.render(cam, params)
+            st = t.stats()
+            out[name] = (rgb8, rad, st.scene_bytes_nodes // 112, st.nodes_visited / st.rays_traced, st.rays_traced)
+    ref = out["optimal"]
+    for name, o in out.items():
+        assert np.array_equal(o[0], ref[0]) and same_bits(o[1], ref[1]) and o[4] == ref[4], name
+    assert out["optimal"][2] < out["parity"][2]          # fewer 4-wide nodes ...
+    assert out["optimal"][3] < out["parity"][3] * 1.02   # ... and no more visits per ray
+    if builder != T.BUILD_HOST_SAH:
+        assert out["three_passes"][3] < out["no_treelets"][3], "treelet restructuring did not lower the node visits per ray"
+
+
 def test_host_built_tree_structure(tracer):
     scene = scenes.cornell_wahoo_scene()
     tracer.upload_scene(scene)

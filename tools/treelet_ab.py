@@ -7,7 +7,8 @@ from gpupathtracer_amd import lib, scenes, types as T
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 inside = scenes.posed_camera(1920, 1080, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
-for name, scene in (("c2", scenes.cornell_wahoo_scene()), ("c3", scenes.blooper_scene()), ("c4", scenes.sphere_stress_scene(5))):
+which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["c2", "c3", "c4"]
+for name, scene in [(n, s) for n, s in (("c2", scenes.cornell_wahoo_scene()), ("c3", scenes.blooper_scene()), ("c4", scenes.sphere_stress_scene(5))) if n in which]:
     cam = scenes.posed_camera(1920, 1080, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0) if name == "c3" else inside
     p = lib.render_params(1920, 1080, 8, spp if name != "c4" else max(spp // 2, 1))
     cases = [("sah", T.BUILD_HOST_SAH, None)]
