@@ -861,3 +861,33 @@ extern "C" int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneIn
     out->bvh_max_leaf = max_leaf;
     return FF_OK;
 }
+
+// Host-only: which of the scene's planes the wall table takes (the table the trace kernels screen in world space, see
+// ff_internal.h WallTable): out_walls receives up to max_walls entries of 6 values {caller's geometry index, normal axis,
+// plane coordinate, centre u, half extent u, ... } - {index, axis, c, cu, hu, cv, hv} as 7 floats each.  Returns the count or a
+// negative FfStatus.  Needs no GPU.
+extern "C" int ff_debug_wall_table(const FfGeometry* host_geometries, int n, float* out_walls7, int max_walls)
+{
+    using namespace ff;
+    clear_error();
+    CompiledScene cs;
+    const int st = compile_scene(host_geometries, n, default_bvh_params(), cs, /*build_bvh=*/false);
+    if (st != FF_OK) return -st;
+    int num_quads = 0;
+    for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
+    WallTable t;
+    build_wall_table(cs.geoms.data(), num_quads, t);
+    int count = 0, i = 0;
+    for (int axis = 0; axis < 3; ++axis)
+        for (int k = 0; k < t.count[axis]; ++k, ++i) {
+            if (out_walls7 && count < max_walls) {
+                const Wall& w = t.w[i];
+                float* o = out_walls7 + (size_t)count * 7;
+                o[0] = (float)cs.geoms[w.geom].orig_index;
+                o[1] = (float)axis;
+                o[2] = w.c; o[3] = w.cu; o[4] = w.hu; o[5] = w.cv; o[6] = w.hv;
+            }
+            ++count;
+        }
+    return count;
+}

@@ -129,6 +129,14 @@ FF_API int ff_debug_download_bvh4(FfState* state, void* nodes4, int max_nodes, i
 /* Host-only dry run of the scene compiler: sizes, BVH shape and a structural self-check.  Needs no GPU. */
 FF_API int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneInfo* out_info);
 
+/* Host-only: the planes the trace kernels screen in WORLD space - those whose model matrix maps the unit quad (kernel.cu:18) onto a
+ * rectangle parallel to two world axes (rotations by multiples of 90 degrees, any translation, scales within 1 : 16): every wall
+ * of a box scene.  Per wall 7 floats {caller's geometry index, normal axis 0/1/2, plane coordinate, centre and half extent along
+ * the next axis, centre and half extent along the one after}; walls sorted by axis.  Returns the number of walls (at most 16 of a
+ * scene's first 32 planes) or minus an FfStatus.  Results never depend on the table: a plane it leaves out, and every hit inside
+ * its margins, goes through the exact reference test.  Needs no GPU. */
+FF_API int ff_debug_wall_table(const FfGeometry* host_geometries, int n, float* out_walls7, int max_walls);
+
 /* ---- rendering (kernel.cu:335-344 + launchPathTrace kernel.cu:218-221) -------------------------- */
 
 /* Headless twin of the per-frame block.  Outputs (either may be NULL):

@@ -185,3 +185,41 @@ def test_save_ppm_matches_reference_format(ff, tmp_path):
     with pytest.raises(L.FireflyError) as e:
         L.save_ppm(str(tmp_path / "no_such_dir" / "x.ppm"), img)
     assert e.value.status == 7  # FF_ERR_IO
+
+
+def test_wall_table_takes_axis_aligned_planes_only(ff):
+    """The wall table (csrc/ff_scene.cpp build_wall_table): the planes the kernels screen in world space.  The C2 box: all six
+    planes, sorted by normal axis, with the rectangles the model matrices give; a plane turned by 45 degrees, a plane stretched
+    1 : 20 and a sphere stay out; quarter turns about any axis (whose cosines glm leaves at 4e-8, not 0) stay in."""
+    import ctypes as C
+    from gpupathtracer_amd import scenes
+    lib = ff.load()
+
+    def table(scene):
+        buf = (C.c_float * (7 * 32))()
+        n = lib.ff_debug_wall_table(scene.geometries, len(scene), buf, 32)
+        assert n >= 0
+        return np.frombuffer(buf, dtype=np.float32)[: 7 * n].reshape(n, 7).copy()
+
+    box = scenes.cornell_wahoo_scene()
+    w = table(box)
+    planes = [i for i, s in enumerate(box._specs) if s[0] == T.GEOM_PLANE]
+    assert sorted(w[:, 0].astype(int).tolist()) == planes
+    assert w[:, 1].astype(int).tolist() == [0, 0, 1, 1, 1, 2]  # left / right, floor / ceiling / light, back
+    by_index = {int(r[0]): r for r in w}
+    back, floor, ceiling, left, right, light = planes
+    assert by_index[back][2] == -2.5 and by_index[floor][2] == -2.5 and by_index[ceiling][2] == 2.5 and by_index[left][2] == -2.5
+    assert np.isclose(by_index[light][2], 2.49) and np.allclose(by_index[light][[4, 6]], 1.0)   # scale 2: half extents 1
+    assert np.allclose(by_index[back][[3, 5]], 0.0) and np.allclose(by_index[back][[4, 6]], 2.5)
+    s = scenes.Scene()
+    grey = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(0.7, 0.7, 0.7))
+    s.add_plane((1, 2, 3), (90, 180, 270), (2, 6, 1), grey)        # quarter turns about all three axes, 1 : 3 : 0.5: in
+    s.add_plane((0, 0, 0), (0, 45, 0), (3, 3, 3), grey)            # oblique: out
+    s.add_plane((0, 1, 0), (90, 0, 0), (1, 20, 1), grey)           # 1 : 20: out
+    s.add_plane((0, 0, -4), (0, 0, 30), (3, 3, 3), grey)           # turned about its own normal by 30 degrees: not a rectangle along the axes: out
+    s.add_sphere(1.0, (0, 0, 0), (0, 0, 0), (1, 1, 1), grey)
+    w = table(s.finalize())
+    assert w.shape[0] == 1 and int(w[0, 0]) == 0
+    # object z (the quad's normal) ends up along one world axis; the quad's 2 x 6 rectangle along the two others
+    assert int(w[0, 1]) in (0, 1, 2) and sorted(np.round(w[0, [4, 6]], 4).tolist()) == [1.0, 3.0]
+    assert lib.ff_debug_wall_table(None, 0, None, 0) < 0
