@@ -356,6 +356,26 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.top_lds_count = s->top_lds_count;
     k.num_scan = s->num_scan;
     k.walls = s->walls;
+    k.cull_mask = nullptr;
+    bool cull = false;
+    {
+        // the padded world box around everything (the records' own boxes are padded); a camera outside it lets the work queue
+        // drop the pixels whose primary ray misses it (acquire_pixel)
+        float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (const GeomRecord& r : s->h_geoms) {
+            if (!(r.wmin[0] <= r.wmax[0])) continue;
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], r.wmin[a]); mx[a] = std::max(mx[a], r.wmax[a]); }
+        }
+        const float cp[3] = { camera->m_position.x, camera->m_position.y, camera->m_position.z };
+        bool outside = false, valid = true;
+        for (int a = 0; a < 3; ++a) {
+            k.scene_min[a] = mn[a];
+            k.scene_max[a] = mx[a];
+            valid = valid && mn[a] <= mx[a] && std::fabs(mn[a]) < 1e30f && std::fabs(mx[a]) < 1e30f;
+            outside = outside || !(cp[a] >= mn[a] && cp[a] <= mx[a]);
+        }
+        cull = prm->trace_mode == FF_TRACE_BVH && valid && outside && !std::getenv("FF_NO_PRIMARY_CULL");
+    }
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
     k.queue = s->d_queue;
@@ -453,6 +473,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         k.tail_start[0] = 0;
         while (k.tail_start[g] < tail_n && g < 8) { k.tail_start[g + 1] = std::min(tail_n, k.tail_start[g] + tail_step); ++g; }
         k.tail_groups = g;
+    }
+    if (cull) {
+        // (after the tail decision: the tail block's samples are stored one by one and are not part of the cull)
+        const int mst = ensure_bytes((void**)&s->d_cull_mask, &s->cull_mask_bytes, ((size_t)k.pix_items / 64 + 2) * sizeof(unsigned long long));
+        if (mst != FF_OK) return mst;
+        FF_HIP(launch_cull_mask(k, s->d_cull_mask, st));
+        k.cull_mask = s->d_cull_mask;
     }
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
@@ -585,6 +612,7 @@ int ff_destroy(FfState* s)
     if (s->d_stage) (void)hipFree(s->d_stage);
     if (s->d_tail_samples) (void)hipFree(s->d_tail_samples);
     if (s->d_stack_spill) (void)hipFree(s->d_stack_spill);
+    if (s->d_cull_mask) (void)hipFree(s->d_cull_mask);
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_mean) (void)hipFree(s->d_mean);

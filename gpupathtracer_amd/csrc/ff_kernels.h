@@ -80,6 +80,11 @@ struct KParams {
     // debugging (FF_DEBUG_LDS_FILL=words,pattern): fill that many 4-byte words of dynamic LDS with the pattern before anything is
     // staged, to expose reads of LDS words nobody wrote
     unsigned debug_lds_words, debug_lds_pattern;
+    // Primary-ray cull: when the camera sits outside the padded box around all geometries (scene_min / scene_max), cull_mask_kernel
+    // marks the pixels whose primary ray misses that box (bit pitem of the mask) and zeroes their block sums; the work queue drops
+    // their items (acquire_pixel).  Null: no cull (camera inside; brute-force mode, which stays the reference's loop as written).
+    const unsigned long long* cull_mask;
+    float scene_min[3], scene_max[3];
     WallTable walls; // axis-aligned planes, screened by a wave-uniform loop (empty for big scenes beyond their first num_scan records)
     // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
     // wall clock (100 MHz ticks since the first wave started; counters[27] holds that epoch), kTimelineBuckets buckets
@@ -128,6 +133,8 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
                         const char** kernel_name = nullptr);
 // Sums every pixel's sample blocks in order, scales by 1/spp and writes radiance / rgb8 (row-major, coalesced).
 hipError_t launch_combine(const KParams& p, hipStream_t stream);
+// Fills mask[pix_items / 64] (see KParams::cull_mask) and zeroes the block sums of the culled pixels.
+hipError_t launch_cull_mask(const KParams& p, unsigned long long* mask, hipStream_t stream);
 // sum = first_frame ? frame : sum + frame; mean = sum * inv_frames (and its 8-bit quantisation); `values` floats.
 hipError_t launch_accumulate(float* sum, const float* frame, float* mean, unsigned char* rgb8, size_t values, int first_frame, float inv_frames,
                              hipStream_t stream);

@@ -1535,7 +1535,7 @@ __device__ __forceinline__ WaveQueue make_wave_queue(const KParams& p)
 // reference's default camera 191 ms instead of 84.)
 // Called by ALL lanes of the wave (Q must stay wave-uniform); `need` marks the lanes that want a pixel.  Returns false for lanes
 // that did not ask or saw the end of the queue.
-__device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& P, WaveQueue& Q, bool need)
+__device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& P, WaveQueue& Q, bool need, unsigned& rays)
 {
     bool got = false, exhausted = !need;
     for (;;) {
@@ -1586,6 +1586,16 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                     pitem = rel / p.whole_blocks;
                     blk = rel - pitem * p.whole_blocks;
                 }
+                // A camera outside the scene (the reference's default one looks at its box from 12.5 units away: 96 % of the frame is
+                // background): cull_mask_kernel has marked the pixels whose primary ray misses the padded box around ALL geometries
+                // and zeroed their block sums - kernel.cu:200-205 has no jitter, every sample of the pixel starts with that ray.
+                // Their items end here: the rays are counted (each is a closest-hit query with the answer "nothing", as in the
+                // brute-force loop, which takes no such shortcut) and the lane asks for the next item.
+                if (p.cull_mask != nullptr && !tail && ((p.cull_mask[pitem >> 6] >> (pitem & 63u)) & 1ull) != 0ull) {
+                    const int s0 = (p.block_begin + (int)blk) * p.block_spp;
+                    rays += (unsigned)(p.shade_mode == FF_SHADE_NORMAL_DEBUG ? 1 : min(p.spp_total, s0 + p.block_spp) - s0);
+                    continue;
+                }
                 const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
                 const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
                 const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
@@ -1612,6 +1622,11 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                     P.pdy = P.ray.dy;
                     P.pdz = P.ray.dz;
                     start_sample(p, P);
+                    // A camera outside the scene (the reference's default one looks at its box from 12.5 units away: 96 % of the
+                    // frame is background): a pixel whose primary ray misses the padded box around ALL geometries has no hit in any
+                    // sample - kernel.cu:200-205 has no jitter, every sample starts with the same ray - so the whole item is a sum of
+                    // zeros.  It is written at once, its rays are counted (each is a closest-hit query with the answer "nothing", as
+                    // in the brute-force loop, which takes no such shortcut), and the lane asks for the next item.
                 }
             }
         }
@@ -1901,7 +1916,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         {
             const bool need = setup && !active && !exhausted;
             if (__ballot(need) != 0ull) {
-                const bool got = acquire_pixel(p, lane, P, Q, need); // (all lanes call: the wave's chunk of the queue is wave state)
+                const bool got = acquire_pixel(p, lane, P, Q, need, cnt.rays); // (all lanes call: the wave's chunk of the queue is wave state)
                 if (need) {
                     active = got;
                     exhausted = !got;
@@ -1957,7 +1972,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_brute_kernel(const KParam
         {
             const bool need = !active && !exhausted;
             if (__ballot(need) != 0ull) {
-                const bool got = acquire_pixel(p, lane, P, Q, need);
+                const bool got = acquire_pixel(p, lane, P, Q, need, cnt.rays);
                 if (need) {
                     active = got;
                     exhausted = !got;
@@ -2028,6 +2043,33 @@ __global__ __launch_bounds__(kBlockThreads) void ray_batch_kernel(const RayBatch
         out.triangleIndex = best.rec >= 0 ? p.tris[best.rec].orig_index : -1;
     }
     p.out[i] = out;
+}
+
+// Which pixels of the local image can the camera not see anything in?  One thread per pixel item (tile-major, like the work
+// queue's): primary ray (kernel.cu:197-205) against the padded box around all geometries - conservative like slab_may_hit:
+// approximate reciprocals, inflated exit, NaN counts as "may hit" - one mask word per 64 items, and the block sums of a culled
+// pixel zeroed for every block of the frame (the combine pass reads them all).
+__global__ void cull_mask_kernel(const KParams p, unsigned long long* mask)
+{
+    const unsigned pitem = blockIdx.x * blockDim.x + threadIdx.x;
+    bool culled = false;
+    if (pitem < p.pix_items) {
+        const int tile = (int)(pitem >> 6), in = (int)(pitem & 63u);
+        const int lx = (tile % p.tiles_per_row) * 8 + (in & 7);
+        const int ly = (tile / p.tiles_per_row) * 8 + (in >> 3);
+        const int strip = ly / p.strip_rows;
+        const int gy = p.y0 + (strip * p.num_parts + p.part) * p.strip_rows + (ly - strip * p.strip_rows);
+        const int gx = p.x0 + lx;
+        if (lx < p.local_width && gx < p.xlim && ly < p.local_rows && gy < p.ylim) {
+            Ray r;
+            primary_ray(p, (unsigned)gx | ((unsigned)gy << 16), r);
+            culled = !slab_may_hit(p.scene_min[0], p.scene_min[1], p.scene_min[2], p.scene_max[0], p.scene_max[1], p.scene_max[2], make_world_slab(r), kInf);
+            if (culled)
+                for (int b = 0; b < p.num_blocks; ++b) p.blocksums[(size_t)pitem * p.num_blocks + b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const unsigned long long word = __ballot(culled);
+    if ((threadIdx.x & 63) == 0 && pitem < ((p.pix_items + 63u) & ~63u)) mask[pitem >> 6] = word;
 }
 
 // Final pass of a frame: add every pixel's sample-block sums in block order, scale by 1/spp (kernel.cu:214 stores the
@@ -2270,6 +2312,13 @@ hipError_t launch_combine(const KParams& p, hipStream_t stream)
     if (p.local_width <= 0 || p.local_rows <= 0) return hipSuccess;
     const dim3 block(256), grid((p.local_width + 255) / 256, p.local_rows);
     hipLaunchKernelGGL(combine_kernel, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cull_mask(const KParams& p, unsigned long long* mask, hipStream_t stream)
+{
+    if (p.pix_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(cull_mask_kernel, dim3((p.pix_items + 255) / 256), dim3(256), 0, stream, p, mask);
     return hipGetLastError();
 }
 

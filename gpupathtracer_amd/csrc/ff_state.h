@@ -33,6 +33,8 @@ struct FfState {
     int top_count = 0, top_depth = 0, top_lds_count = 0;
     int stack_entries = 1;                // traversal stack entries per lane the BVH kernels need for this scene
     int stack_lds_levels = 1;             // ... of which this many live in LDS (finalize_layout); the rest in d_stack_spill
+    unsigned long long* d_cull_mask = nullptr; // primary-ray cull: one bit per pixel item (KParams::cull_mask)
+    size_t cull_mask_bytes = 0;
     int* d_stack_spill = nullptr;         // (stack_entries - stack_lds_levels) x launch threads ints
     size_t stack_spill_bytes = 0;
     int scene_block_threads = 0, lds_cap = 0; // BVH kernel workgroup size and LDS node slots chosen for this scene (finalize_layout)

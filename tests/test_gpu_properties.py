@@ -439,3 +439,33 @@ def test_failed_scene_allocation_leaves_no_half_uploaded_scene(monkeypatch, buil
                 got = t.render(cam, params)
                 assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
     assert failures >= 5  # records, triangles, normals, nodes, 4-wide nodes, parents
+
+
+def test_primary_rays_that_miss_the_scene_box_are_dropped_at_the_queue(tracer, monkeypatch):
+    """A camera outside the padded box around all geometries (the reference's default one, kernel.cu:312-321): pixels whose primary
+    ray misses that box are written as zero sums when their work item is fetched (csrc/ff_kernels.hip acquire_pixel) instead of
+    being traced sample by sample.  The frame, and the number of rays counted, equal the brute-force kernel's (which takes no such
+    shortcut) and the same kernel's with the shortcut off; in path mode, in the reference's own shade mode, on tiles and strips,
+    and with enough samples for several blocks per pixel."""
+    scene = scenes.cornell_wahoo_scene()
+    for (w, h), cam_args in (((320, 180), None), ((200, 150), dict(position=(9.0, 4.0, 11.0), yaw=-130.0, pitch=-15.0))):
+        cam = scenes.default_camera(w, h) if cam_args is None else scenes.posed_camera(w, h, **cam_args)
+        tracer.upload_scene(scene)
+        for params in (lib.render_params(w, h, 6, 5, 3), lib.render_params(w, h, 3, 130, 4), lib.render_params(w, h, 1, 1, shade_mode=T.SHADE_NORMAL_DEBUG)):
+            bvh = tracer.render(cam, params)
+            rays = tracer.stats().rays_traced
+            assert (bvh[1] == 0).all(axis=2).mean() > 0.5  # most of the frame is background
+            params.trace_mode = T.TRACE_BRUTE_FORCE
+            brute = tracer.render(cam, params)
+            assert rays == tracer.stats().rays_traced
+            assert np.array_equal(bvh[0], brute[0]) and np.array_equal(bvh[1].view(np.uint32), brute[1].view(np.uint32))
+            params.trace_mode = T.TRACE_BVH
+            monkeypatch.setenv("FF_NO_PRIMARY_CULL", "1")
+            off = tracer.render(cam, params)
+            monkeypatch.delenv("FF_NO_PRIMARY_CULL")
+            assert rays == tracer.stats().rays_traced and np.array_equal(bvh[1].view(np.uint32), off[1].view(np.uint32))
+        # a tile across the silhouette of the box and the strips of a three-part frame carry the full frame's pixels
+        params = lib.render_params(w, h, 4, 3, 8)
+        full = tracer.render(cam, params)
+        tile = tracer.render_tile(cam, params, w // 4, h // 4, w // 2, h // 2)
+        assert np.array_equal(tile[1].view(np.uint32), full[1][h // 4:h // 4 + h // 2, w // 4:w // 4 + w // 2].view(np.uint32))
