@@ -298,6 +298,7 @@ def main():
     barrier_sync()
     t0 = time.perf_counter()
     rays = 0
+    answered = 0
     kernel_ms = 0.0
     launches = 0
     frame_ms = []
@@ -306,6 +307,7 @@ def main():
         st = step()
         frame_ms.append((time.perf_counter() - tf) * 1e3)
         rays += st.rays_traced
+        answered += st.rays_answered
         kernel_ms += st.kernel_ms
         launches += st.kernel_launches
     barrier_sync()
@@ -317,11 +319,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float(rays)], dtype=torch.float64, device=red_dev)
+        agg = torch.tensor([float(rays), float(answered)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        total_rays = agg[0].item()
+        total_rays, total_answered = agg[0].item(), agg[1].item()
     else:
-        total_rays = float(rays)
+        total_rays, total_answered = float(rays), float(answered)
 
     # ---- companion figure (untimed region, N = 1 only): the same frame from the reference's default camera ----
     companion = None
@@ -383,7 +385,14 @@ def main():
                 "workload": f"{scene_name}, {args.width}x{args.height}, "
                             f"{args.bounces} bounces, {args.spp} spp, camera={args.camera}, trace={args.trace_mode}, seed {args.seed}",
                 "scene": args.scene,
-                "rays_per_frame": int(total_rays / args.steps), "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
+                "rays_per_frame": int(total_rays / args.steps),
+                # of those path segments, the ones answered without a traversal: the repeated primary rays of a sample block (every
+                # sample of a pixel starts with the same ray, kernel.cu:200-205: traced once per block) and the
+                # primary rays of pixels whose view of the scene box is empty (camera outside the scene).  `value` counts all path
+                # segments, as in every round; `traversed_Mrays_per_s` only those that went through the closest-hit machinery
+                "rays_answered_without_traversal_per_frame": int(total_answered / args.steps),
+                "traversed_Mrays_per_s": round((total_rays - total_answered) / elapsed / 1e6, 2),
+                "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
                 "gather": gather if gather_note is None else f"{gather} ({gather_note})",
             },
             "roofline": roof,

@@ -357,6 +357,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.num_scan = s->num_scan;
     k.walls = s->walls;
     k.cull_mask = nullptr;
+    s->pending_culled_rays_per_pixel = 0;
     bool cull = false;
     {
         // the padded world box around everything (the records' own boxes are padded); a camera outside it lets the work queue
@@ -395,6 +396,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const uint64_t max_useful = ((uint64_t)k.pix_items * (uint64_t)num_blocks + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
+    k.primary_cache = nullptr;
+    if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !std::getenv("FF_NO_PRIMARY_REUSE")) {
+        // one slot per thread of the launch for the closest hit of its sample block's primary ray (trace_bvh_kernel)
+        const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)grid * (size_t)block_threads * sizeof(float4));
+        if (cst != FF_OK) return cst;
+        k.primary_cache = s->d_primary_cache;
+    }
     if (prm->trace_mode == FF_TRACE_BVH && s->stack_lds_levels < s->stack_entries) {
         // the stack levels that did not get LDS (finalize_layout): one int per level and thread of the launch
         const int st = ensure_bytes((void**)&s->d_stack_spill, &s->stack_spill_bytes,
@@ -480,6 +488,8 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         if (mst != FF_OK) return mst;
         FF_HIP(launch_cull_mask(k, s->d_cull_mask, st));
         k.cull_mask = s->d_cull_mask;
+        // (a culled pixel's whole-block items are dropped; with a fine-grained tail its last block is still traced sample by sample)
+        s->pending_culled_rays_per_pixel = debug ? 1u : (unsigned)(spp - (tail_mode ? tail_n : 0));
     }
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
@@ -523,6 +533,8 @@ int render_finish(FfState* s)
         return fail(FF_ERR_HIP, "the traversal loop guard cut %llu queries short (a malformed or absurdly deep tree): the frame is not valid", c[0]);
     s->stats.rays_traced = 0;
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_traced += s->h_counters[kRaySlotStride * (kRaySlotFirst + j)];
+    s->stats.rays_answered = s->h_counters[kCulledPixelsWord] * s->pending_culled_rays_per_pixel; // primary rays of culled pixels
+    for (int j = 0; j < kRaySlots; ++j) s->stats.rays_answered += s->h_counters[kAnsweredWord + kRaySlotStride * j]; // + repeated primaries
     s->raw_counters[0] = s->stats.rays_traced;
     s->stats.nodes_visited = c[1];
     s->stats.tris_tested = c[2];
@@ -613,6 +625,7 @@ int ff_destroy(FfState* s)
     if (s->d_tail_samples) (void)hipFree(s->d_tail_samples);
     if (s->d_stack_spill) (void)hipFree(s->d_stack_spill);
     if (s->d_cull_mask) (void)hipFree(s->d_cull_mask);
+    if (s->d_primary_cache) (void)hipFree(s->d_primary_cache);
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_mean) (void)hipFree(s->d_mean);

@@ -84,6 +84,8 @@ struct KParams {
     // marks the pixels whose primary ray misses that box (bit pitem of the mask) and zeroes their block sums; the work queue drops
     // their items (acquire_pixel).  Null: no cull (camera inside; brute-force mode, which stays the reference's loop as written).
     const unsigned long long* cull_mask;
+    // Primary-hit cache (BVH mega-kernel): 3 float4 per thread of the launch, lane-strided; null: every primary ray is traced
+    float4* primary_cache;
     float scene_min[3], scene_max[3];
     WallTable walls; // axis-aligned planes, screened by a wave-uniform loop (empty for big scenes beyond their first num_scan records)
     // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
@@ -94,6 +96,9 @@ struct KParams {
 // The ray count of a launch is added up in kRaySlots 64-bit slots of the counter block, kRaySlotStride words apart, from slot
 // kRaySlotFirst on (the first 256 bytes hold the named counters): counters[kRaySlotStride * (kRaySlotFirst + j)].
 constexpr int kRaySlots = 30, kRaySlotFirst = 2, kRaySlotStride = 16;
+// ... and next to each ray slot the count of those rays that were answered without a traversal: counters[kAnsweredWord + kRaySlotStride * j]
+constexpr int kAnsweredWord = kRaySlotStride * kRaySlotFirst + 1;
+constexpr int kCulledPixelsWord = kRaySlotStride * kRaySlotFirst + 2; // cull_mask_kernel: pixels whose items the queue drops
 constexpr int kCounterWords = 512; // 64-bit words of the counter block (4 KiB; the work-queue counters follow)
 constexpr int kTimelineBuckets = 1024;
 // Work queue: up to kQueueCounters counters, 4 KiB apart so that they sit in different memory channels (atomics on one address

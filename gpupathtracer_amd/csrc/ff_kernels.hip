@@ -57,6 +57,7 @@ struct BestId {
 
 struct Counters {
     unsigned rays, nodes, tris, planes; // per lane and launch (flushed into 64-bit device counters)
+    unsigned reused;   // WAVE-uniform (a scalar register): of the wave's `rays`, the repeated primary rays answered from the block's cache
     // occupancy probes (instrumented launches only): wave-level rounds of each phase.  The active-lane totals of the
     // phases are the counters above (nodes = inner-step lanes, tris = triangle-test lanes, planes, rays).
     unsigned inner_rounds, leaf_rounds, tri_rounds, plane_rounds, segment_rounds;
@@ -310,8 +311,9 @@ struct LdsBase {
     int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j
     int stack_base; // uint index of this lane's stack slot 0 (in units of 4 bytes from ff_smem)
     int stack_depth; // entries per lane kept in LDS
-    int* spill;      // deeper entries of this lane: entry e >= stack_depth at spill[(e - stack_depth) * spill_stride] (null: none)
-    size_t spill_stride;
+    int* spill;      // deeper entries: entry e >= stack_depth of thread g of the launch at spill[(e - stack_depth) * threads + g] (null: none).
+                     // Wave-uniform (scalar registers); the lane's own address is formed in the rare branch that needs it
+    int block;       // workgroup size
     int stride;     // uints between consecutive stack entries of one lane (= block size)
     int geom_base;  // uint4 index of geometry record 0
     int num_quads;  // geometry records [0, num_quads) are planes; [num_quads, num_planes) spheres; meshes follow
@@ -343,8 +345,8 @@ __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int
     // Stack entries beyond the LDS levels live in global memory, lane-strided over the whole launch (the host trades the deepest,
     // rarely used stack levels for tree nodes in LDS: finalize_layout).  (Fetching the pointer from the kernel arguments only when
     // an entry spills, instead of keeping it in registers, was measured: no gain.)
-    L.spill_stride = (size_t)gridDim.x * (size_t)block;
-    L.spill = spill ? spill + (size_t)blockIdx.x * (size_t)block + (size_t)tid : nullptr;
+    L.spill = spill;
+    L.block = block;
     L.num_scan = num_scan;
     L.geoms_g = reinterpret_cast<const float4*>(geoms);
     L.top_first = top_first;
@@ -412,13 +414,13 @@ template <class LDS>
 __device__ __forceinline__ void stack_push(const LDS& L, int sp, int v)
 {
     if (__builtin_expect(sp < L.stack_depth, 1)) reinterpret_cast<int*>(ff_smem)[L.stack_base + sp * L.stride] = v;
-    else L.spill[(size_t)(sp - L.stack_depth) * L.spill_stride] = v;
+    else L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + threadIdx.x] = v;
 }
 template <class LDS>
 __device__ __forceinline__ int stack_pop(const LDS& L, int sp)
 {
     if (__builtin_expect(sp < L.stack_depth, 1)) return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride];
-    return L.spill[(size_t)(sp - L.stack_depth) * L.spill_stride];
+    return L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + threadIdx.x];
 }
 
 // kernel.cu:138 with the geometry record gathered from LDS by a lane-varying index (same arithmetic as object_space_ray).
@@ -1774,6 +1776,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
     // (spread over kRaySlots addresses 128 bytes apart: thousands of waves end within microseconds of each other in a short
     // launch, and atomics on one address are served one after the other, ~10 ns each; the host adds the slots)
     if (lane == 0 && rays) atomicAdd(&p.counters[kRaySlotStride * (kRaySlotFirst + (blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], rays);
+    if (lane == 0 && cnt.reused) atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], (unsigned long long)cnt.reused);
     if (cnt.guard_hits != 0ull && lane == 0) atomicAdd(&p.counters[0], (unsigned long long)__popcll(cnt.guard_hits)); // (never in a healthy launch)
     if (stats) {
         const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
@@ -1862,6 +1865,9 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.node_base = 0; S.lds_first = 0; S.lds_count = 0; S.tl_sp = 0;
     S.pnx = 0; S.pny = 1; S.pnz = 2; S.pfx = 3; S.pfy = 4; S.pfz = 5;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
+    bool cached = false; // this lane's slot of the primary-hit cache holds the hit of its current block's primary ray
+    // (the slot's address is formed where it is used - a few instructions - rather than held in two registers through the loop)
+    auto cache_slot = [&](int k) { return p.primary_cache + ((size_t)k * gridDim.x + blockIdx.x) * (size_t)BLOCK + (size_t)tid; };
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
@@ -1899,18 +1905,46 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         }
         Best best;
         bool hit = false;
-        if (setup && inflight) {
+        bool shade_now = setup && inflight; // lanes with a finished query
+        if (shade_now) {
             finish_segment(L, p.tris, P.ray, S, best);
             hit = best.geom >= 0;
         }
+        // Every sample of a pixel starts with the same ray (kernel.cu:200-205: the pixel's corner, no jitter), so the closest hit of
+        // a sample block's FIRST primary ray is the closest hit of all of them.  The lane parks it in its slot of a global array
+        // (36 bytes, lane-strided: the registers of the traversal loop are spoken for) and the block's other samples start from
+        // there: no query, no traversal, no resolution - one fifth of the headline frame's path segments.
+        if (p.primary_cache != nullptr && shade_now && P.b == 0 && !cached) {
+            *cache_slot(0) = make_float4(best.dist, best.px, best.py, best.pz);
+            *cache_slot(1) = make_float4(best.cx, best.cy, best.cz, __int_as_float(best.geom));
+            *cache_slot(2) = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
+            cached = true;
+        }
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
-        if (setup && inflight) {
-            MaterialRef M;
-            M.global = BIG == 2 ? p.geoms + (hit ? best.geom : 0) : nullptr;
-            M.geom_base = L.geom_base;
-            M.g = best.geom;
-            active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
-            inflight = false;
+        // Shade; a lane whose path ended and whose next sample starts with the cached hit shades again at once (its new path's first
+        // segment is already answered), until every shading lane has a ray to trace, a first-of-block primary, or no work left.
+        while (__ballot(shade_now) != 0ull) { // (every pass ends a sample of each lane in it: at most a block's samples)
+            if (shade_now) {
+                MaterialRef M;
+                M.global = BIG == 2 ? p.geoms + (hit ? best.geom : 0) : nullptr;
+                M.geom_base = L.geom_base;
+                M.g = best.geom;
+                active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
+                inflight = false;
+                shade_now = active && P.b == 0 && cached; // a new sample of the same block, its primary hit known
+                if (shade_now) {
+                    const float4 c0 = *cache_slot(0), c1 = *cache_slot(1), c2 = *cache_slot(2);
+                    best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
+                    best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
+                    best.geom = __float_as_int(c1.w);
+                    best.rec = __float_as_int(c2.x);
+                    hit = best.geom >= 0;
+                    cnt.rays += 1; // a path segment like any other, answered without a traversal (counted apart below)
+                }
+            }
+            const unsigned reused_now = (unsigned)__popcll(__ballot(shade_now));
+            cnt.reused += reused_now;
+            if (STATS && p.timeline) tl_count += reused_now; // (the launch timeline counts every path segment where it completes)
         }
         if (STATS) t2 = __builtin_amdgcn_s_memtime();
         {
@@ -1920,6 +1954,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 if (need) {
                     active = got;
                     exhausted = !got;
+                    cached = false; // a new block: its first primary ray is traced
                     if (STATS && exhausted) atomicMax(&p.counters[23], ~(unsigned long long)wall_clock64()); // (complemented) first lane to find the queue empty
                 }
             }
@@ -2069,7 +2104,10 @@ __global__ void cull_mask_kernel(const KParams p, unsigned long long* mask)
         }
     }
     const unsigned long long word = __ballot(culled);
-    if ((threadIdx.x & 63) == 0 && pitem < ((p.pix_items + 63u) & ~63u)) mask[pitem >> 6] = word;
+    if ((threadIdx.x & 63) == 0 && pitem < ((p.pix_items + 63u) & ~63u)) {
+        mask[pitem >> 6] = word;
+        if (word) atomicAdd(&p.counters[kCulledPixelsWord], (unsigned long long)__popcll(word)); // (the host turns pixels into rays)
+    }
 }
 
 // Final pass of a frame: add every pixel's sample-block sums in block order, scale by 1/spp (kernel.cu:214 stores the

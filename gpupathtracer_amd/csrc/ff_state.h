@@ -35,6 +35,8 @@ struct FfState {
     int stack_lds_levels = 1;             // ... of which this many live in LDS (finalize_layout); the rest in d_stack_spill
     unsigned long long* d_cull_mask = nullptr; // primary-ray cull: one bit per pixel item (KParams::cull_mask)
     size_t cull_mask_bytes = 0;
+    float4* d_primary_cache = nullptr; // KParams::primary_cache
+    size_t primary_cache_bytes = 0;
     int* d_stack_spill = nullptr;         // (stack_entries - stack_lds_levels) x launch threads ints
     size_t stack_spill_bytes = 0;
     int scene_block_threads = 0, lds_cap = 0; // BVH kernel workgroup size and LDS node slots chosen for this scene (finalize_layout)
@@ -100,6 +102,7 @@ struct FfState {
     // a frame enqueued by render_enqueue and not yet finished by render_finish
     int pending_launches = 0;
     uint32_t pending_flags = 0;
+    unsigned pending_culled_rays_per_pixel = 0; // primary-ray cull: rays each culled pixel stands for in FfStats::rays_answered
     bool pending = false;
     // fault injection for tests (FF_DEBUG_FAIL_ALLOC=k: the k-th scene allocation of every upload reports out-of-memory)
     int debug_fail_alloc = -1, alloc_countdown = -1;

@@ -159,7 +159,7 @@ typedef struct FfRenderParams {
 
 /* Filled by ff_stats() after a render call. Counts are for the LAST ff_render* call on this state. */
 typedef struct FfStats {
-    uint64_t rays_traced;        /* closest-hit queries executed on device (wave-reduced counter) */
+    uint64_t rays_traced;        /* closest-hit queries = path segments of the frame, counted on the device (wave-reduced counter) */
     uint64_t nodes_visited;      /* visits of 4-wide BVH nodes (112 B each); only when stats collection is on */
     uint64_t tris_tested;        /* ray/triangle tests (48 B each); only when stats collection is on */
     uint64_t planes_tested;      /* ray/plane tests */
@@ -169,6 +169,9 @@ typedef struct FfStats {
     uint32_t flags;              /* FF_STATS_* bits about how the frame was scheduled */
     uint64_t scene_bytes_nodes;  /* device bytes of BVH nodes */
     uint64_t scene_bytes_tris;   /* device bytes of triangle records */
+    uint64_t rays_answered;      /* ... of rays_traced: path segments answered without a traversal - primary rays of pixels whose view of the
+                                    scene box is empty (camera outside the scene) and the repeated primary rays of a sample block (every sample
+                                    of a pixel starts with the same ray, kernel.cu:200-205); 0 in brute-force mode */
 } FfStats;
 #define FF_STATS_TAIL_ITEMS 1u             /* the frame's last sample block was handed out as fine-grained items (multi-part frames) */
 #define FF_STATS_TAIL_SKIPPED_TOO_LARGE 2u /* ... was wanted, but its per-sample buffer would pass 16 GiB: rendered with whole-block items */

@@ -469,3 +469,37 @@ def test_primary_rays_that_miss_the_scene_box_are_dropped_at_the_queue(tracer, m
         full = tracer.render(cam, params)
         tile = tracer.render_tile(cam, params, w // 4, h // 4, w // 2, h // 2)
         assert np.array_equal(tile[1].view(np.uint32), full[1][h // 4:h // 4 + h // 2, w // 4:w // 4 + w // 2].view(np.uint32))
+
+
+def test_repeated_primary_rays_are_answered_from_the_block_cache(tracer, monkeypatch):
+    """Every sample of a pixel starts with the same ray (kernel.cu:200-205 has no jitter): the BVH kernel traces the primary ray of
+    a sample block once, parks its closest hit and starts the block's other samples from there (csrc/ff_kernels.hip
+    trace_bvh_kernel).  Same bits and the same number of path segments as with the cache off (FF_NO_PRIMARY_REUSE=1) and as the
+    brute-force kernel, which traces every one of them; FfStats::rays_answered counts exactly the repeated ones: samples minus
+    blocks per pixel (camera inside the box: no pixel is culled); with diffuse, mirror and glass surfaces, one bounce (every
+    path is its primary segment), partial last blocks, several launches per frame and interpolated normals."""
+    cam = scenes.posed_camera(96, 64, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    for scene in (scenes.cornell_wahoo_scene(), scenes.cornell_glass_scene()):
+        tracer.upload_scene(scene)
+        for bounces, spp, per_launch, shade in ((6, 70, 0, T.SHADE_DIFFUSE_PATH), (1, 130, 0, T.SHADE_DIFFUSE_PATH), (4, 200, 64, T.SHADE_DIFFUSE_PATH_SMOOTH), (3, 1100, 0, T.SHADE_DIFFUSE_PATH)):
+            params = lib.render_params(96, 64, bounces, spp, 21, T.TRACE_BVH, shade, T.GRID_FULL, per_launch)
+            on = tracer.render(cam, params)
+            st = tracer.stats()
+            block_spp = 64 * ((spp + 1023) // 1024)
+            blocks = (spp + block_spp - 1) // block_spp
+            tail = st.flags & T.FF_STATS_TAIL_ITEMS
+            if not tail:
+                assert st.rays_answered == 96 * 64 * (spp - blocks), (bounces, spp, st.rays_answered)
+            else:
+                assert 0 < st.rays_answered <= 96 * 64 * (spp - blocks)
+            monkeypatch.setenv("FF_NO_PRIMARY_REUSE", "1")
+            off = tracer.render(cam, params)
+            st_off = tracer.stats()
+            monkeypatch.delenv("FF_NO_PRIMARY_REUSE")
+            assert st_off.rays_answered == 0 and st_off.rays_traced == st.rays_traced
+            assert np.array_equal(on[0], off[0]) and np.array_equal(on[1].view(np.uint32), off[1].view(np.uint32))
+            if spp <= 200:
+                params.trace_mode = T.TRACE_BRUTE_FORCE
+                brute = tracer.render(cam, params)
+                assert tracer.stats().rays_traced == st.rays_traced and tracer.stats().rays_answered == 0
+                assert np.array_equal(on[1].view(np.uint32), brute[1].view(np.uint32))
