@@ -299,6 +299,7 @@ def main():
     t0 = time.perf_counter()
     rays = 0
     answered = 0
+    cut_short = 0
     kernel_ms = 0.0
     launches = 0
     frame_ms = []
@@ -308,6 +309,7 @@ def main():
         frame_ms.append((time.perf_counter() - tf) * 1e3)
         rays += st.rays_traced
         answered += st.rays_answered
+        cut_short += st.rays_cut_short
         kernel_ms += st.kernel_ms
         launches += st.kernel_launches
     barrier_sync()
@@ -319,11 +321,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float(rays), float(answered)], dtype=torch.float64, device=red_dev)
+        agg = torch.tensor([float(rays), float(answered), float(cut_short)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        total_rays, total_answered = agg[0].item(), agg[1].item()
+        total_rays, total_answered, total_cut = agg[0].item(), agg[1].item(), agg[2].item()
     else:
-        total_rays, total_answered = float(rays), float(answered)
+        total_rays, total_answered, total_cut = float(rays), float(answered), float(cut_short)
 
     # ---- companion figure (untimed region, N = 1 only): the same frame from the reference's default camera ----
     companion = None
@@ -392,6 +394,9 @@ def main():
                 # segments, as in every round; `traversed_Mrays_per_s` only those that went through the closest-hit machinery
                 "rays_answered_without_traversal_per_frame": int(total_answered / args.steps),
                 "traversed_Mrays_per_s": round((total_rays - total_answered) / elapsed / 1e6, 2),
+                # ... and the last segments of paths that ended after the planes were screened: only an emitter can still add radiance
+                # there, the scene's emitters are planes, and none was among the query's candidates (the meshes were not walked)
+                "rays_cut_short_after_the_planes_per_frame": int(total_cut / args.steps),
                 "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
                 "gather": gather if gather_note is None else f"{gather} ({gather_note})",
             },

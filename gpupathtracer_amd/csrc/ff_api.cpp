@@ -356,6 +356,21 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.top_lds_count = s->top_lds_count;
     k.num_scan = s->num_scan;
     k.walls = s->walls;
+    k.emitter_mask = 0u;
+    k.cut_last = 0;
+    if (prm->trace_mode == FF_TRACE_BVH && !debug && !std::getenv("FF_NO_LAST_BOUNCE_CUT")) {
+        // The last segment of a path adds radiance only when it ends on an emitter.  If every emitter is one of the analytic records
+        // all queries screen before anything else (all planes and spheres of a small scene, the scan planes of a big one), a
+        // last-bounce query that holds no emitter after that screening is over (scan_records).
+        const int screened = s->num_geoms > kChunkGeometries ? s->num_scan : s->num_planes;
+        bool all_screened = true;
+        for (int i = 0; i < s->num_geoms; ++i) {
+            if (s->h_geoms[i].bxdf_type != FF_BXDF_EMITTER) continue;
+            if (i < screened && i < 32) k.emitter_mask |= 1u << i;
+            else all_screened = false;
+        }
+        k.cut_last = all_screened ? 1 : 0;
+    }
     k.cull_mask = nullptr;
     s->pending_culled_rays_per_pixel = 0;
     bool cull = false;
@@ -397,6 +412,8 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
     k.primary_cache = nullptr;
+    k.reuse_quorum = 1;
+    if (const char* e = std::getenv("FF_REUSE_QUORUM")) k.reuse_quorum = std::max(1, std::min(65, std::atoi(e)));
     if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !std::getenv("FF_NO_PRIMARY_REUSE")) {
         // one slot per thread of the launch for the closest hit of its sample block's primary ray (trace_bvh_kernel)
         const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)grid * (size_t)block_threads * sizeof(float4));
@@ -535,6 +552,8 @@ int render_finish(FfState* s)
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_traced += s->h_counters[kRaySlotStride * (kRaySlotFirst + j)];
     s->stats.rays_answered = s->h_counters[kCulledPixelsWord] * s->pending_culled_rays_per_pixel; // primary rays of culled pixels
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_answered += s->h_counters[kAnsweredWord + kRaySlotStride * j]; // + repeated primaries
+    s->stats.rays_cut_short = 0;
+    for (int j = 0; j < kRaySlots; ++j) s->stats.rays_cut_short += s->h_counters[kCutShortWord + kRaySlotStride * j];
     s->raw_counters[0] = s->stats.rays_traced;
     s->stats.nodes_visited = c[1];
     s->stats.tris_tested = c[2];

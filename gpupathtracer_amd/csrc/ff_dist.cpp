@@ -614,6 +614,8 @@ int multi_render_core(FfMulti* m, const FfCamera* camera, const FfRenderParams* 
         if (st != FF_OK) return st;
         if (i == 0) FF_HIP(hipStreamSynchronize(m->streams[0]));
         m->stats.rays_traced += s->stats.rays_traced;
+        m->stats.rays_answered += s->stats.rays_answered;
+        m->stats.rays_cut_short += s->stats.rays_cut_short;
         m->stats.nodes_visited += s->stats.nodes_visited;
         m->stats.tris_tested += s->stats.tris_tested;
         m->stats.planes_tested += s->stats.planes_tested;

@@ -86,6 +86,12 @@ struct KParams {
     const unsigned long long* cull_mask;
     // Primary-hit cache (BVH mega-kernel): 3 float4 per thread of the launch, lane-strided; null: every primary ray is traced
     float4* primary_cache;
+    int reuse_quorum; // lanes of a wave that must wait with a parked primary hit before the wave spends an extra shading pass on them
+    // Last segment of a path (bounce index bounces - 1): only an emitter can still add radiance (shade_and_advance).  cut_last != 0:
+    // every emitter of the scene is among the analytic records all queries screen first, bit g of emitter_mask says which; a
+    // last-bounce query that holds no emitter after that screening ends there (scan_records / begin_segment).
+    unsigned emitter_mask;
+    int cut_last;
     float scene_min[3], scene_max[3];
     WallTable walls; // axis-aligned planes, screened by a wave-uniform loop (empty for big scenes beyond their first num_scan records)
     // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
@@ -98,6 +104,7 @@ struct KParams {
 constexpr int kRaySlots = 30, kRaySlotFirst = 2, kRaySlotStride = 16;
 // ... and next to each ray slot the count of those rays that were answered without a traversal: counters[kAnsweredWord + kRaySlotStride * j]
 constexpr int kAnsweredWord = kRaySlotStride * kRaySlotFirst + 1;
+constexpr int kCutShortWord = kRaySlotStride * kRaySlotFirst + 3;     // (+ kRaySlotStride * j) last-bounce queries that ended after the analytic records
 constexpr int kCulledPixelsWord = kRaySlotStride * kRaySlotFirst + 2; // cull_mask_kernel: pixels whose items the queue drops
 constexpr int kCounterWords = 512; // 64-bit words of the counter block (4 KiB; the work-queue counters follow)
 constexpr int kTimelineBuckets = 1024;

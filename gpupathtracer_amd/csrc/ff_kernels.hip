@@ -57,6 +57,7 @@ struct BestId {
 
 struct Counters {
     unsigned rays, nodes, tris, planes; // per lane and launch (flushed into 64-bit device counters)
+    unsigned cut;      // WAVE-uniform: last-bounce queries that ended after the analytic records (no emitter among the candidates)
     unsigned reused;   // WAVE-uniform (a scalar register): of the wave's `rays`, the repeated primary rays answered from the block's cache
     // occupancy probes (instrumented launches only): wave-level rounds of each phase.  The active-lane totals of the
     // phases are the counters above (nodes = inner-step lanes, tris = triangle-test lanes, planes, rays).
@@ -783,9 +784,15 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
 // Anything within the margins (quad edges, t ~ 0, |n.d| ~ 1e-7) is decided by the exact reference test at once.
 // Scenes of up to 32 geometries (the reference has 5): every query screens all planes / spheres and collects its candidate meshes
 // in a bit mask (larger scenes walk the geometry tree instead: enter_top / geom_step).
+// Bit mask of the records in the query's candidate slots (records 0..31: the analytic records screened before anything else).
+__device__ __forceinline__ unsigned holds(const Segment& S)
+{
+    return (S.pend.geom >= 0 ? 1u << (S.pend.geom & 31) : 0u) | (S.best.geom >= 0 ? 1u << (S.best.geom & 31) : 0u);
+}
+
 template <bool STATS, class LDS>
 __device__ __forceinline__ void scan_records(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
-                                           const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+                                           const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt, bool cut, unsigned emitters)
 {
     const int prim_end = num_planes;
     const float wlen = __builtin_amdgcn_rcpf(inv_length(wr)); // |world direction| (1 for the integrator's rays)
@@ -826,6 +833,14 @@ __device__ __forceinline__ void scan_records(const LDS& L, const WallTable& W, c
             cur = nxt;
         }
     }
+    {
+        // A path's last segment adds radiance only if it ends on an emitter.  Every analytic record has been screened: the nearest
+        // of them is one of the (at most two) candidates held.  If neither is an emitter, the closest hit of the whole query is a
+        // non-emitter or nothing, whatever the meshes hold: the query ends here.
+        const bool over = cut && (holds(S) & emitters) == 0u;
+        if (over) S.meshes = 0u;
+        cnt.cut += (unsigned)__popcll(__ballot(over));
+    }
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
     if (STATS) {
         const unsigned long long tb3 = __builtin_amdgcn_s_memtime();
@@ -862,7 +877,8 @@ __device__ __forceinline__ void scan_walls(const LDS& L, const WallTable& W, con
 // Start a closest-hit query: empty candidate slots, then the geometry records (small scenes) or the root of the geometry tree.
 template <bool STATS, class LDS>
 __device__ __forceinline__ void begin_segment(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
-                                              const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt)
+                                              const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt, bool cut = false,
+                                              unsigned emitters = 0u)
 {
     S.best.dist = kInf; // kernel.cu:131
     S.best.geom = -1;
@@ -879,11 +895,14 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const WallTable& W, 
         // big scenes: the query starts at the root of the tree over the geometries, in world space
         S.meshes = 0u;
         if (L.num_scan > 0) scan_walls<STATS>(L, W, tris, wr, S, cnt);
+        const bool over = cut && (holds(S) & emitters) == 0u; // (see scan_records: here every emitter is among the scanned planes)
+        cnt.cut += (unsigned)__popcll(__ballot(over));
+        if (over) return;
         enter_top(L, wr, S);
         S.cur = 0;
         return;
     }
-    scan_records<STATS>(L, W, geoms, num_geoms, num_planes, tris, wr, S, cnt);
+    scan_records<STATS>(L, W, geoms, num_geoms, num_planes, tris, wr, S, cnt, cut, emitters);
 }
 
 // Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
@@ -1129,9 +1148,16 @@ __device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restr
     S.resume = 0;
     if (STATS) probe_round(cnt.leaf_rounds);
     unsigned long long tl_wait = 0, tl_test = 0, tl0 = 0;
+    // The next triangle's record is requested before this one is tested (its wait overlaps the arithmetic; the last round asks
+    // for its own record again, a hit in the L1).
+    float4 An = tp[3 * k], E1n = tp[3 * k + 1], E2n = tp[3 * k + 2];
     for (; k < count; ++k) {
         if (STATS) tl0 = __builtin_amdgcn_s_memtime();
-        const float4 A = tp[3 * k], E1 = tp[3 * k + 1], E2 = tp[3 * k + 2];
+        const float4 A = An, E1 = E1n, E2 = E2n;
+        {
+            const int kn = min(k + 1, count - 1);
+            An = tp[3 * kn]; E1n = tp[3 * kn + 1]; E2n = tp[3 * kn + 2];
+        }
         if (STATS) {
             // (instrumented launches only: the wait for the three loads is made explicit so that it can be told from the arithmetic)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1777,6 +1803,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
     // launch, and atomics on one address are served one after the other, ~10 ns each; the host adds the slots)
     if (lane == 0 && rays) atomicAdd(&p.counters[kRaySlotStride * (kRaySlotFirst + (blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], rays);
     if (lane == 0 && cnt.reused) atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], (unsigned long long)cnt.reused);
+    if (lane == 0 && cnt.cut) atomicAdd(&p.counters[kCutShortWord + kRaySlotStride * ((blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) % kRaySlots)], (unsigned long long)cnt.cut);
     if (cnt.guard_hits != 0ull && lane == 0) atomicAdd(&p.counters[0], (unsigned long long)__popcll(cnt.guard_hits)); // (never in a healthy launch)
     if (stats) {
         const unsigned long long n = wave_sum((unsigned long long)cnt.nodes), t = wave_sum((unsigned long long)cnt.tris),
@@ -1920,10 +1947,30 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             *cache_slot(2) = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
             cached = true;
         }
+        // A lane that waits with a new sample whose primary hit is parked (see below) joins this iteration's shading.
+        bool from_cache = setup && !inflight && active && P.b == 0 && cached;
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
-        // Shade; a lane whose path ended and whose next sample starts with the cached hit shades again at once (its new path's first
-        // segment is already answered), until every shading lane has a ray to trace, a first-of-block primary, or no work left.
-        while (__ballot(shade_now) != 0ull) { // (every pass ends a sample of each lane in it: at most a block's samples)
+        // Shade; a lane whose path ended and whose next sample starts with the parked hit shades again - at once if at least
+        // reuse_quorum lanes of the wave are in that position (a pass costs the wave the same whatever the number of lanes in it),
+        // else together with the next iteration's finished queries - until every shading lane has a ray to trace, a first-of-block
+        // primary ray, a parked hit to wait with, or no work left.
+        for (;;) { // (every pass ends a sample of each lane in it: at most a block's samples)
+            if (from_cache) {
+                const float4 c0 = *cache_slot(0), c1 = *cache_slot(1), c2 = *cache_slot(2);
+                best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
+                best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
+                best.geom = __float_as_int(c1.w);
+                best.rec = __float_as_int(c2.x);
+                hit = best.geom >= 0;
+                cnt.rays += 1; // a path segment like any other, answered without a traversal (counted apart below)
+                shade_now = true;
+            }
+            {
+                const unsigned reused_now = (unsigned)__popcll(__ballot(from_cache));
+                cnt.reused += reused_now;
+                if (STATS && p.timeline) tl_count += reused_now; // (the launch timeline counts every path segment where it completes)
+            }
+            if (__ballot(shade_now) == 0ull) break;
             if (shade_now) {
                 MaterialRef M;
                 M.global = BIG == 2 ? p.geoms + (hit ? best.geom : 0) : nullptr;
@@ -1931,20 +1978,10 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 M.g = best.geom;
                 active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
                 inflight = false;
-                shade_now = active && P.b == 0 && cached; // a new sample of the same block, its primary hit known
-                if (shade_now) {
-                    const float4 c0 = *cache_slot(0), c1 = *cache_slot(1), c2 = *cache_slot(2);
-                    best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
-                    best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
-                    best.geom = __float_as_int(c1.w);
-                    best.rec = __float_as_int(c2.x);
-                    hit = best.geom >= 0;
-                    cnt.rays += 1; // a path segment like any other, answered without a traversal (counted apart below)
-                }
             }
-            const unsigned reused_now = (unsigned)__popcll(__ballot(shade_now));
-            cnt.reused += reused_now;
-            if (STATS && p.timeline) tl_count += reused_now; // (the launch timeline counts every path segment where it completes)
+            const bool waiting = shade_now && active && P.b == 0 && cached; // a new sample of the same block, its primary hit parked
+            shade_now = false;
+            from_cache = waiting && __popcll(__ballot(waiting)) >= p.reuse_quorum;
         }
         if (STATS) t2 = __builtin_amdgcn_s_memtime();
         {
@@ -1960,14 +1997,14 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             }
         }
         if (STATS) t3 = __builtin_amdgcn_s_memtime();
-        if (setup && active) {
+        if (setup && active && !(P.b == 0 && cached)) { // (a lane with a parked primary hit waits for the next shading pass)
             if (STATS) probe_round(cnt.segment_rounds);
-            begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt);
+            begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt, p.cut_last != 0 && P.b == p.bounces - 1, p.emitter_mask);
             cnt.rays += 1;
             inflight = true;
         }
         if (STATS) t4 = __builtin_amdgcn_s_memtime();
-        if (__ballot(inflight) == 0ull) break;
+        if (__ballot(inflight || (active && P.b == 0 && cached)) == 0ull) break; // (a lane that waits with a parked hit still has work)
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
         // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
         if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes);

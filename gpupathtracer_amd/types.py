@@ -108,7 +108,7 @@ class FfStats(C.Structure):
         ("rays_traced", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("planes_tested", C.c_uint64),
         ("kernel_ms", C.c_double), ("total_ms", C.c_double),
         ("kernel_launches", C.c_uint32), ("flags", C.c_uint32),
-        ("scene_bytes_nodes", C.c_uint64), ("scene_bytes_tris", C.c_uint64), ("rays_answered", C.c_uint64),
+        ("scene_bytes_nodes", C.c_uint64), ("scene_bytes_tris", C.c_uint64), ("rays_answered", C.c_uint64), ("rays_cut_short", C.c_uint64),
     ]
 
 

@@ -172,6 +172,9 @@ typedef struct FfStats {
     uint64_t rays_answered;      /* ... of rays_traced: path segments answered without a traversal - primary rays of pixels whose view of the
                                     scene box is empty (camera outside the scene) and the repeated primary rays of a sample block (every sample
                                     of a pixel starts with the same ray, kernel.cu:200-205); 0 in brute-force mode */
+    uint64_t rays_cut_short;     /* ... of rays_traced: last segments of paths (bounce index bounces - 1) whose query ended after the planes and
+                                    spheres because no emitter was among the candidates - only an emitter can still add radiance there and
+                                    every emitter of the scene is a plane or a sphere; 0 in brute-force mode */
 } FfStats;
 #define FF_STATS_TAIL_ITEMS 1u             /* the frame's last sample block was handed out as fine-grained items (multi-part frames) */
 #define FF_STATS_TAIL_SKIPPED_TOO_LARGE 2u /* ... was wanted, but its per-sample buffer would pass 16 GiB: rendered with whole-block items */

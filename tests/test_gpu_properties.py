@@ -498,8 +498,52 @@ def test_repeated_primary_rays_are_answered_from_the_block_cache(tracer, monkeyp
             monkeypatch.delenv("FF_NO_PRIMARY_REUSE")
             assert st_off.rays_answered == 0 and st_off.rays_traced == st.rays_traced
             assert np.array_equal(on[0], off[0]) and np.array_equal(on[1].view(np.uint32), off[1].view(np.uint32))
+            # FF_REUSE_QUORUM: lanes with a parked hit wait for the next iteration's shading unless that many of them are ready
+            # (65: they always wait, also when no other lane of the wave has a query left)
+            for quorum in ("5", "65"):
+                monkeypatch.setenv("FF_REUSE_QUORUM", quorum)
+                held = tracer.render(cam, params)
+                st_q = tracer.stats()
+                monkeypatch.delenv("FF_REUSE_QUORUM")
+                assert st_q.rays_answered == st.rays_answered and st_q.rays_traced == st.rays_traced
+                assert np.array_equal(on[1].view(np.uint32), held[1].view(np.uint32))
             if spp <= 200:
                 params.trace_mode = T.TRACE_BRUTE_FORCE
                 brute = tracer.render(cam, params)
                 assert tracer.stats().rays_traced == st.rays_traced and tracer.stats().rays_answered == 0
                 assert np.array_equal(on[1].view(np.uint32), brute[1].view(np.uint32))
+
+
+def test_last_bounce_queries_end_after_the_planes_when_no_emitter_is_held(tracer, monkeypatch):
+    """The last segment of a path (bounce index bounces - 1) adds radiance only when it ends on an emitter
+    (csrc/ff_kernels.hip shade_and_advance; oracle/ff_oracle.c restates the loop).  When every emitter of the scene is a plane
+    or a sphere - records every query screens before any mesh - a last-bounce query that holds no emitter after that screening
+    ends there (scan_records; FfStats::rays_cut_short).  Same bits and the same number of path segments as with the shortcut off
+    (FF_NO_LAST_BOUNCE_CUT=1) and as the brute-force kernel; an emitter MESH switches it off; so does the normal-debug shade."""
+    cam = scenes.posed_camera(96, 64, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    lit_mesh = scenes.Scene()
+    lit_mesh.add_mesh(scenes.load_mesh("cube"), (0.2, 1.2, -0.4), (0, 30, 0), (0.8, 0.3, 0.8), scenes.make_bxdf(T.BXDF_EMITTER, emissive=(1, 0.9, 0.8), intensity=3.0))
+    lit_mesh.add_mesh(scenes.load_mesh("wahoo"), (0, -2.4, 0), (0, 0, 0), (0.28, 0.28, 0.28), scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(0.8, 0.8, 0.2)))
+    scenes._box(lit_mesh).finalize()
+    cases = [(scenes.cornell_wahoo_scene(), True), (scenes.cornell_glass_scene(), True), (scenes.cornell_spheres_scene(), True), (lit_mesh, False)]
+    for scene, cuts in cases:
+        tracer.upload_scene(scene)
+        for bounces, spp, shade in ((1, 3, T.SHADE_DIFFUSE_PATH), (2, 5, T.SHADE_DIFFUSE_PATH), (8, 6, T.SHADE_DIFFUSE_PATH), (4, 70, T.SHADE_DIFFUSE_PATH_SMOOTH)):
+            params = lib.render_params(96, 64, bounces, spp, 77, T.TRACE_BVH, shade)
+            on = tracer.render(cam, params)
+            st = tracer.stats()
+            assert (st.rays_cut_short > 0) == cuts, (bounces, spp, st.rays_cut_short)
+            assert st.rays_cut_short <= 96 * 64 * spp  # at most one last segment per path
+            monkeypatch.setenv("FF_NO_LAST_BOUNCE_CUT", "1")
+            off = tracer.render(cam, params)
+            st_off = tracer.stats()
+            monkeypatch.delenv("FF_NO_LAST_BOUNCE_CUT")
+            assert st_off.rays_cut_short == 0 and st_off.rays_traced == st.rays_traced
+            assert np.array_equal(on[0], off[0]) and np.array_equal(on[1].view(np.uint32), off[1].view(np.uint32))
+            params.trace_mode = T.TRACE_BRUTE_FORCE
+            brute = tracer.render(cam, params)
+            assert tracer.stats().rays_traced == st.rays_traced and tracer.stats().rays_cut_short == 0
+            assert np.array_equal(on[1].view(np.uint32), brute[1].view(np.uint32))
+    tracer.upload_scene(scenes.cornell_wahoo_scene())
+    tracer.render(cam, lib.render_params(96, 64, 1, 1, 0, T.TRACE_BVH, T.SHADE_NORMAL_DEBUG))
+    assert tracer.stats().rays_cut_short == 0
