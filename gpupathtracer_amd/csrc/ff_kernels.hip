@@ -516,8 +516,8 @@ struct Segment {
                                // geometry tree, the mesh's own entries sit above them (0 otherwise)
     int node_base;             // the current mesh's first node in the global 4-wide node array
     int lds_first, lds_count;  // its nodes [0, lds_count) sit in LDS from LDS node index lds_first on
-    int pnx, pny, pnz;         // box planes (quarters of a node) the ray enters through: min planes 0/1/2 or max planes 3/4/5 by the sign of its direction
-    int pfx, pfy, pfz;         // ... and leaves through
+    int bnx, bny, bnz;         // box planes (quarters of a node) the ray enters through, as byte offsets into the LDS node image (set_box_planes)
+    int bfx, bfy, bfz;         // ... and leaves through
     Ray osr;                   // object-space ray of the current mesh
     float ix, iy, iz, ox, oy, oz; // 1/d and -o/d of osr (box tests)
     float scale;               // object-space t per unit of world distance
@@ -965,6 +965,21 @@ __device__ __forceinline__ void pop_subtree(const LDS& L, const uint4* __restric
     pop_entry(L, nodes4, S, stack_pop(L, S.sp - 1));
 }
 
+// The quarters of a node the ray enters through (min planes 0/1/2 or max planes 3/4/5 by the signs of its direction) and leaves
+// through, as BYTE offsets into the LDS node image (quarter k of node j: (k * node_cap + j) * 16): the inner step forms each of its
+// six addresses with one add.  (Nodes outside LDS: inner_step derives the quarters from the same signs.)
+template <class LDS>
+__device__ __forceinline__ void set_box_planes(const LDS& L, Segment& S)
+{
+    const int q = L.node_cap * 16;
+    S.bnx = S.ix < 0.0f ? 3 * q : 0;
+    S.bny = S.iy < 0.0f ? 4 * q : q;
+    S.bnz = S.iz < 0.0f ? 5 * q : 2 * q;
+    S.bfx = 3 * q - S.bnx;
+    S.bfy = 5 * q - S.bny;
+    S.bfz = 7 * q - S.bnz;
+}
+
 // Put the lane's cursor on the root of mesh g's tree: object-space ray (kernel.cu:138), slab constants, box planes by the
 // signs of the direction.
 template <class LDS>
@@ -980,12 +995,7 @@ __device__ __forceinline__ void enter_mesh(const LDS& L, int g, const Ray& wr, S
     S.ox = -S.osr.ox * S.ix;
     S.oy = -S.osr.oy * S.iy;
     S.oz = -S.osr.oz * S.iz;
-    S.pnx = S.ix < 0.0f ? 3 : 0;
-    S.pny = S.iy < 0.0f ? 4 : 1;
-    S.pnz = S.iz < 0.0f ? 5 : 2;
-    S.pfx = 3 - S.pnx;
-    S.pfy = 5 - S.pny;
-    S.pfz = 7 - S.pnz;
+    set_box_planes(L, S);
     S.scale = len * inv_length(wr); // object-space t per unit of world distance
     refresh_tbound(S);
     S.mesh = g;
@@ -1018,12 +1028,7 @@ __device__ __forceinline__ void enter_top(const LDS& L, const Ray& wr, Segment& 
     S.ox = -wr.ox * S.ix;
     S.oy = -wr.oy * S.iy;
     S.oz = -wr.oz * S.iz;
-    S.pnx = S.ix < 0.0f ? 3 : 0;
-    S.pny = S.iy < 0.0f ? 4 : 1;
-    S.pnz = S.iz < 0.0f ? 5 : 2;
-    S.pfx = 3 - S.pnx;
-    S.pfy = 5 - S.pny;
-    S.pfz = 7 - S.pnz;
+    set_box_planes(L, S);
     S.scale = inv_length(wr); // ray parameter per unit of world distance (ff_intersect_rays takes rays of any length)
     refresh_tbound(S);
     S.mesh = -1;
@@ -1075,23 +1080,24 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
     const int rel = S.cur;
     uint4 nx, ny, nz, fx, fy, fz, lk;
     if ((unsigned)rel < (unsigned)S.lds_count) {
-        const int j = S.lds_first + rel;
-        nx = ff_smem[j + S.pnx * L.node_cap];
-        ny = ff_smem[j + S.pny * L.node_cap];
-        nz = ff_smem[j + S.pnz * L.node_cap];
-        fx = ff_smem[j + S.pfx * L.node_cap];
-        fy = ff_smem[j + S.pfy * L.node_cap];
-        fz = ff_smem[j + S.pfz * L.node_cap];
-        lk = ff_smem[j + 6 * L.node_cap];
+        const char* const nb = reinterpret_cast<const char*>(ff_smem) + (S.lds_first + rel) * 16;
+        nx = *reinterpret_cast<const uint4*>(nb + S.bnx);
+        ny = *reinterpret_cast<const uint4*>(nb + S.bny);
+        nz = *reinterpret_cast<const uint4*>(nb + S.bnz);
+        fx = *reinterpret_cast<const uint4*>(nb + S.bfx);
+        fy = *reinterpret_cast<const uint4*>(nb + S.bfy);
+        fz = *reinterpret_cast<const uint4*>(nb + S.bfz);
+        lk = *reinterpret_cast<const uint4*>(nb + 6 * 16 * L.node_cap);
         FF_PIN4(lk);
     } else {
         const uint4* p = nodes4 + (size_t)(S.node_base + rel) * kNodeVec4;
-        nx = p[S.pnx];
-        ny = p[S.pny];
-        nz = p[S.pnz];
-        fx = p[S.pfx];
-        fy = p[S.pfy];
-        fz = p[S.pfz];
+        const int gx = S.ix < 0.0f ? 3 : 0, gy = S.iy < 0.0f ? 4 : 1, gz = S.iz < 0.0f ? 5 : 2; // (set_box_planes)
+        nx = p[gx];
+        ny = p[gy];
+        nz = p[gz];
+        fx = p[3 - gx];
+        fy = p[5 - gy];
+        fz = p[7 - gz];
         lk = p[6];
         FF_PIN4(lk);
     }
@@ -1890,7 +1896,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.scale = 1.f;
     S.tbound = 0.f;
     S.node_base = 0; S.lds_first = 0; S.lds_count = 0; S.tl_sp = 0;
-    S.pnx = 0; S.pny = 1; S.pnz = 2; S.pfx = 3; S.pfy = 4; S.pfz = 5;
+    S.bnx = S.bny = S.bnz = S.bfx = S.bfy = S.bfz = 0;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
     bool cached = false; // this lane's slot of the primary-hit cache holds the hit of its current block's primary ray
     // (the slot's address is formed where it is used - a few instructions - rather than held in two registers through the loop)
