@@ -791,7 +791,7 @@ __device__ __forceinline__ unsigned holds(const Segment& S)
 }
 
 template <bool STATS, class LDS>
-__device__ __forceinline__ void scan_records(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+__device__ __forceinline__ bool scan_records(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                            const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt, bool cut, unsigned emitters)
 {
     const int prim_end = num_planes;
@@ -833,19 +833,17 @@ __device__ __forceinline__ void scan_records(const LDS& L, const WallTable& W, c
             cur = nxt;
         }
     }
-    {
-        // A path's last segment adds radiance only if it ends on an emitter.  Every analytic record has been screened: the nearest
-        // of them is one of the (at most two) candidates held.  If neither is an emitter, the closest hit of the whole query is a
-        // non-emitter or nothing, whatever the meshes hold: the query ends here.
-        const bool over = cut && (holds(S) & emitters) == 0u;
-        if (over) S.meshes = 0u;
-        cnt.cut += (unsigned)__popcll(__ballot(over));
-    }
+    // A path's last segment adds radiance only if it ends on an emitter.  Every analytic record has been screened: the nearest
+    // of them is one of the (at most two) candidates held.  If neither is an emitter, the closest hit of the whole query is a
+    // non-emitter or nothing, whatever the meshes hold: the query ends here.  (Returned, and counted by the caller at wave level.)
+    const bool over = cut && (holds(S) & emitters) == 0u;
+    if (over) S.meshes = 0u;
     if (STATS && S.meshes == 0u) cnt.no_mesh += 1;
     if (STATS) {
         const unsigned long long tb3 = __builtin_amdgcn_s_memtime();
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_b1 += tb1 - tb0; cnt.t_b2 += tb2 - tb1; cnt.t_b3 += tb3 - tb2; }
     }
+    return over;
 }
 
 template <class LDS>
@@ -875,8 +873,9 @@ __device__ __forceinline__ void scan_walls(const LDS& L, const WallTable& W, con
 }
 
 // Start a closest-hit query: empty candidate slots, then the geometry records (small scenes) or the root of the geometry tree.
+// Returns true for a last-bounce query (`cut`) that is already over (scan_records).
 template <bool STATS, class LDS>
-__device__ __forceinline__ void begin_segment(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
+__device__ __forceinline__ bool begin_segment(const LDS& L, const WallTable& W, const GeomRecord* __restrict__ geoms, int num_geoms, int num_planes,
                                               const TriRecord* __restrict__ tris, const Ray& wr, Segment& S, Counters& cnt, bool cut = false,
                                               unsigned emitters = 0u)
 {
@@ -896,13 +895,12 @@ __device__ __forceinline__ void begin_segment(const LDS& L, const WallTable& W, 
         S.meshes = 0u;
         if (L.num_scan > 0) scan_walls<STATS>(L, W, tris, wr, S, cnt);
         const bool over = cut && (holds(S) & emitters) == 0u; // (see scan_records: here every emitter is among the scanned planes)
-        cnt.cut += (unsigned)__popcll(__ballot(over));
-        if (over) return;
+        if (over) return true;
         enter_top(L, wr, S);
         S.cur = 0;
-        return;
+        return false;
     }
-    scan_records<STATS>(L, W, geoms, num_geoms, num_planes, tris, wr, S, cnt, cut, emitters);
+    return scan_records<STATS>(L, W, geoms, num_geoms, num_planes, tris, wr, S, cnt, cut, emitters);
 }
 
 // Box-pruning bound of the current mesh: refreshed whenever the lane's best/pending distance or its mesh changes, so the
@@ -1947,12 +1945,24 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         // a sample block's FIRST primary ray is the closest hit of all of them.  The lane parks it in its slot of a global array
         // (36 bytes, lane-strided: the registers of the traversal loop are spoken for) and the block's other samples start from
         // there: no query, no traversal, no resolution - one fifth of the headline frame's path segments.
+        unsigned skipped = 0u;
         if (p.primary_cache != nullptr && shade_now && P.b == 0 && !cached) {
             *cache_slot(0) = make_float4(best.dist, best.px, best.py, best.pz);
             *cache_slot(1) = make_float4(best.cx, best.cy, best.cz, __int_as_float(best.geom));
             *cache_slot(2) = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
             cached = true;
+            if (!hit && P.bitem >= 0) {
+                // Nothing in view: every sample of the block adds zero to its sum.  This sample becomes the block's last; the lane
+                // books the path segments of the others (each a query answered with "nothing") itself - it is rare.
+                skipped = (unsigned)(P.send - 1 - P.s);
+                P.s = P.send - 1;
+                if (skipped) {
+                    cnt.rays += skipped;
+                    atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + tid / kWave) % kRaySlots)], (unsigned long long)skipped);
+                }
+            }
         }
+        if (STATS && p.timeline) tl_count += (unsigned)wave_sum((unsigned long long)skipped); // (the timeline counts every path segment)
         // A lane that waits with a new sample whose primary hit is parked (see below) joins this iteration's shading.
         bool from_cache = setup && !inflight && active && P.b == 0 && cached;
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
@@ -2003,12 +2013,14 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             }
         }
         if (STATS) t3 = __builtin_amdgcn_s_memtime();
+        bool over = false; // a last-bounce query that ended after the planes
         if (setup && active && !(P.b == 0 && cached)) { // (a lane with a parked primary hit waits for the next shading pass)
             if (STATS) probe_round(cnt.segment_rounds);
-            begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt, p.cut_last != 0 && P.b == p.bounces - 1, p.emitter_mask);
+            over = begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt, p.cut_last != 0 && P.b == p.bounces - 1, p.emitter_mask);
             cnt.rays += 1;
             inflight = true;
         }
+        cnt.cut += (unsigned)__popcll(__ballot(over));
         if (STATS) t4 = __builtin_amdgcn_s_memtime();
         if (__ballot(inflight || (active && P.b == 0 && cached)) == 0ull) break; // (a lane that waits with a parked hit still has work)
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
