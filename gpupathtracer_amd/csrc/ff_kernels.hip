@@ -1666,22 +1666,25 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
     return got;
 }
 
-// Shade the finished segment and advance the path.  Returns true when the lane still owns its pixel (either the path
-// continues with a new ray in P.ray, or the next sample's primary ray was generated), false when the pixel is finished.
-// SPECULAR = false: the caller guarantees a scene without MIRROR / GLASS surfaces and their code drops out.
+// Shading comes in two steps so that the trace kernel can run the expensive one once per iteration (trace_bvh_kernel):
+//   settle_hit: what the finished segment means for the path - it ends (on an emitter, on nothing, at the last bounce; the sample's
+//     radiance goes to the block sum and the next sample or the end of the block follows) or it goes on from this hit;
+//   scatter:    the next ray of a path that goes on (normal, random numbers, new direction).
+// settle_hit returns kPixelDone (the lane gives the pixel up), kNewSample (the next sample's primary ray is in P.ray) or kGoesOn
+// (scatter must follow with the same hit).  SPECULAR = false: the caller guarantees a scene without MIRROR / GLASS surfaces.
+enum { kPixelDone = 0, kNewSample = 1, kGoesOn = 2 };
 template <bool SPECULAR = true>
-__device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
+__device__ __forceinline__ int settle_hit(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
 {
     const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
-    bool path_done = true;
     // Radiance of the path: it is zero until the path ends on an emitter (the only light transport here), so it is not
     // carried across segments; "0 + beta*Le" of the integrator is beta*Le bit for bit.
     float Lx = 0.f, Ly = 0.f, Lz = 0.f;
     if (hit) {
-        float nx, ny, nz;
-        world_normal(M, best, debug_shade, nx, ny, nz);
         if (debug_shade) {
             // shade(), kernel.cu:178-184
+            float nx, ny, nz;
+            world_normal(M, best, true, nx, ny, nz);
             Lx = fabsf(nx); Ly = fabsf(ny); Lz = fabsf(nz);
         } else if (mat_bxdf(M) == FF_BXDF_EMITTER) {
             // utilities.h:96-103: two-sided emitter, m_emissiveColor * m_intensity
@@ -1690,96 +1693,19 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
             Ly = 0.f + P.by * emission.y;
             Lz = 0.f + P.bz * emission.z;
         } else {
-            // MIRROR: perfect reflection, throughput *= m_specularColor (the record's tint slot holds it).  GLASS: smooth
-            // dielectric, Fresnel-weighted choice between reflection and refraction (oracle/ff_oracle.c is the definition).
-            // Everything else is diffuse (utilities.h:109): cosine-weighted sampling, so f*cos/pdf = albedo.
-            const int bxdf = mat_bxdf(M);
-            const bool mirror = SPECULAR && bxdf == FF_BXDF_MIRROR, glass = SPECULAR && bxdf == FF_BXDF_GLASS;
+            // MIRROR: throughput *= m_specularColor (the record's tint slot holds it).  GLASS: the tint depends on the choice between
+            // reflection and refraction (scatter).  Everything else is diffuse (utilities.h:109): cosine-weighted sampling, so
+            // f*cos/pdf = albedo.
+            const bool glass = SPECULAR && mat_bxdf(M) == FF_BXDF_GLASS;
             const float4 albedo = mat_f4(M, 12);
             if (!glass) {
                 P.bx = P.bx * albedo.x;
                 P.by = P.by * albedo.y;
                 P.bz = P.bz * albedo.z;
             }
-            if (P.b != p.bounces - 1) {
-                const float ninv = ieee_rcp(ieee_sqrt(dot3(nx, ny, nz, nx, ny, nz)));
-                float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
-                bool flipped = false;
-                if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; flipped = true; }
-                float wox, woy, woz;
-                float sx = ux, sy = uy, sz = uz; // the next ray starts on this side of the surface
-                if (glass) {
-                    const float dx = P.ray.dx, dy = P.ray.dy, dz = P.ray.dz;
-                    const float ior = albedo.w;
-                    const float eta = flipped ? ior : ieee_rcp(ior);
-                    const float ci = -dot3(ux, uy, uz, dx, dy, dz);
-                    const float s2 = (eta * eta) * (1.0f - ci * ci);
-                    bool reflect = true;
-                    float ct = 0.f;
-                    if (s2 < 1.0f) {
-                        ct = ieee_sqrt(1.0f - s2);
-                        const float a = eta * ci, bq = eta * ct;
-                        const float rs = (a - ct) / (a + ct), rp = (ci - bq) / (ci + bq);
-                        const float F = 0.5f * (rs * rs + rp * rp);
-                        unsigned r0, r1;
-                        const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
-                        philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
-                        const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
-                        reflect = u1 < F;
-                    }
-                    float tx, ty, tz;
-                    if (reflect) {
-                        const float k2 = 2.0f * ci;
-                        wox = dx + k2 * ux;
-                        woy = dy + k2 * uy;
-                        woz = dz + k2 * uz;
-                        tx = albedo.x; ty = albedo.y; tz = albedo.z;
-                    } else {
-                        const float k = eta * ci - ct;
-                        wox = eta * dx + k * ux;
-                        woy = eta * dy + k * uy;
-                        woz = eta * dz + k * uz;
-                        const float4 tr = mat_f4(M, 13);
-                        tx = tr.x; ty = tr.y; tz = tr.z;
-                        sx = -ux; sy = -uy; sz = -uz;
-                    }
-                    P.bx = P.bx * tx;
-                    P.by = P.by * ty;
-                    P.bz = P.bz * tz;
-                } else if (mirror) {
-                    const float k2 = 2.0f * dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz);
-                    wox = P.ray.dx - k2 * ux;
-                    woy = P.ray.dy - k2 * uy;
-                    woz = P.ray.dz - k2 * uz;
-                } else {
-                    unsigned r0, r1;
-                    const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
-                    philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
-                    const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
-                    float wlx, wly, wlz;
-                    cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
-                    // orthonormal basis (Duff et al. 2017)
-                    const float sign = copysignf(1.0f, uz);
-                    const float aa = -ieee_rcp(sign + uz); // -1 / x == -(1 / x)
-                    const float bb = (ux * uy) * aa;
-                    const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
-                    const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
-                    wox = (t0 * wlx + s0 * wly) + ux * wlz;
-                    woy = (t1 * wlx + s1 * wly) + uy * wlz;
-                    woz = (t2 * wlx + s2 * wly) + uz * wlz;
-                }
-                P.ray.ox = best.px + sx * kRayEps;
-                P.ray.oy = best.py + sy * kRayEps;
-                P.ray.oz = best.pz + sz * kRayEps;
-                P.ray.dx = wox; // unit local direction in an orthonormal basis: used as is (|wo| = 1 +- 1e-6)
-                P.ray.dy = woy;
-                P.ray.dz = woz;
-                ++P.b;
-                path_done = false;
-            }
+            if (P.b != p.bounces - 1) return kGoesOn;
         }
     }
-    if (!path_done) return true;
     if (P.bitem < 0) {
         // tail item: every sample is stored on its own; the combine pass adds the block's samples in order
         p.tail_samples[~P.bitem] = make_float4(Lx, Ly, Lz, 0.f);
@@ -1792,11 +1718,107 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
     ++P.s;
     if (P.s < P.send && !debug_shade) {
         start_sample(p, P);
-        return true;
+        return kNewSample;
     }
     // sample block finished: its sum goes to the block buffer (the combine kernel adds a pixel's blocks in order)
     if (P.bitem >= 0) p.blocksums[P.bitem] = make_float4(P.ax, P.ay, P.az, 0.f);
-    return false;
+    return kPixelDone;
+}
+
+// The next ray of a path that goes on from `best` (settle_hit returned kGoesOn; the throughput already carries the surface's
+// albedo, glass excepted).  MIRROR: perfect reflection.  GLASS: smooth dielectric, Fresnel-weighted choice between reflection and
+// refraction (oracle/ff_oracle.c is the definition).  Everything else: cosine-weighted direction about the world normal.
+template <bool SPECULAR = true>
+__device__ __forceinline__ void scatter(const KParams& p, const Best& best, const MaterialRef& M, Path& P)
+{
+    float nx, ny, nz;
+    world_normal(M, best, false, nx, ny, nz);
+    const int bxdf = mat_bxdf(M);
+    const bool mirror = SPECULAR && bxdf == FF_BXDF_MIRROR, glass = SPECULAR && bxdf == FF_BXDF_GLASS;
+    const float4 albedo = mat_f4(M, 12);
+    const float ninv = ieee_rcp(ieee_sqrt(dot3(nx, ny, nz, nx, ny, nz)));
+    float ux = nx * ninv, uy = ny * ninv, uz = nz * ninv;
+    bool flipped = false;
+    if (dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz) > 0.0f) { ux = -ux; uy = -uy; uz = -uz; flipped = true; }
+    float wox, woy, woz;
+    float sx = ux, sy = uy, sz = uz; // the next ray starts on this side of the surface
+    if (glass) {
+        const float dx = P.ray.dx, dy = P.ray.dy, dz = P.ray.dz;
+        const float ior = albedo.w;
+        const float eta = flipped ? ior : ieee_rcp(ior);
+        const float ci = -dot3(ux, uy, uz, dx, dy, dz);
+        const float s2 = (eta * eta) * (1.0f - ci * ci);
+        bool reflect = true;
+        float ct = 0.f;
+        if (s2 < 1.0f) {
+            ct = ieee_sqrt(1.0f - s2);
+            const float a = eta * ci, bq = eta * ct;
+            const float rs = (a - ct) / (a + ct), rp = (ci - bq) / (ci + bq);
+            const float F = 0.5f * (rs * rs + rp * rp);
+            unsigned r0, r1;
+            const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
+            philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
+            const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
+            reflect = u1 < F;
+        }
+        float tx, ty, tz;
+        if (reflect) {
+            const float k2 = 2.0f * ci;
+            wox = dx + k2 * ux;
+            woy = dy + k2 * uy;
+            woz = dz + k2 * uz;
+            tx = albedo.x; ty = albedo.y; tz = albedo.z;
+        } else {
+            const float k = eta * ci - ct;
+            wox = eta * dx + k * ux;
+            woy = eta * dy + k * uy;
+            woz = eta * dz + k * uz;
+            const float4 tr = mat_f4(M, 13);
+            tx = tr.x; ty = tr.y; tz = tr.z;
+            sx = -ux; sy = -uy; sz = -uz;
+        }
+        P.bx = P.bx * tx;
+        P.by = P.by * ty;
+        P.bz = P.bz * tz;
+    } else if (mirror) {
+        const float k2 = 2.0f * dot3(ux, uy, uz, P.ray.dx, P.ray.dy, P.ray.dz);
+        wox = P.ray.dx - k2 * ux;
+        woy = P.ray.dy - k2 * uy;
+        woz = P.ray.dz - k2 * uz;
+    } else {
+        unsigned r0, r1;
+        const unsigned gpix = (P.gxy >> 16) * (unsigned)p.width + (P.gxy & 0xFFFFu);
+        philox2x32_10(gpix, ((unsigned)P.s << 8) | ((unsigned)P.b & 0xFFu), p.key, r0, r1);
+        const float u1 = (float)(r0 >> 8) * 5.9604644775390625e-08f;
+        float wlx, wly, wlz;
+        cosine_sample(u1, r1 >> 8, wlx, wly, wlz);
+        // orthonormal basis (Duff et al. 2017)
+        const float sign = copysignf(1.0f, uz);
+        const float aa = -ieee_rcp(sign + uz); // -1 / x == -(1 / x)
+        const float bb = (ux * uy) * aa;
+        const float t0 = 1.0f + ((sign * ux) * ux) * aa, t1 = sign * bb, t2 = -sign * ux;
+        const float s0 = bb, s1 = sign + (uy * uy) * aa, s2 = -uy;
+        wox = (t0 * wlx + s0 * wly) + ux * wlz;
+        woy = (t1 * wlx + s1 * wly) + uy * wlz;
+        woz = (t2 * wlx + s2 * wly) + uz * wlz;
+    }
+    P.ray.ox = best.px + sx * kRayEps;
+    P.ray.oy = best.py + sy * kRayEps;
+    P.ray.oz = best.pz + sz * kRayEps;
+    P.ray.dx = wox; // unit local direction in an orthonormal basis: used as is (|wo| = 1 +- 1e-6)
+    P.ray.dy = woy;
+    P.ray.dz = woz;
+    ++P.b;
+}
+
+// Both steps in a row (the brute-force kernel).  Returns true when the lane still owns its pixel (either the path continues with
+// a new ray in P.ray, or the next sample's primary ray was generated), false when the pixel is finished.
+template <bool SPECULAR = true>
+__device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
+{
+    const int r = settle_hit<SPECULAR>(p, best, hit, M, P);
+    if (r == kGoesOn) scatter<SPECULAR>(p, best, M, P);
+    return r != kPixelDone;
 }
 
 __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const Counters& cnt, bool stats)
@@ -1966,10 +1988,13 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         // A lane that waits with a new sample whose primary hit is parked (see below) joins this iteration's shading.
         bool from_cache = setup && !inflight && active && P.b == 0 && cached;
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
-        // Shade; a lane whose path ended and whose next sample starts with the parked hit shades again - at once if at least
-        // reuse_quorum lanes of the wave are in that position (a pass costs the wave the same whatever the number of lanes in it),
-        // else together with the next iteration's finished queries - until every shading lane has a ray to trace, a first-of-block
-        // primary ray, a parked hit to wait with, or no work left.
+        // Shading in two steps (settle_hit / scatter).  A lane whose path ended and whose next sample starts with the parked hit
+        // settles again - at once if at least reuse_quorum lanes of the wave are in that position, else together with the next
+        // iteration's finished queries - until every settling lane has a path that goes on from a hit, a first-of-block primary ray
+        // to trace, a parked hit to wait with, or no work left.  Settling is cheap (a material lookup, a few multiplications); the
+        // expensive step - normal, random numbers, new direction - then runs ONCE, for the lanes that go on from the hit they just
+        // found and for those that go on from their parked primary hit alike.
+        bool settle_now = shade_now, goes_on = false;
         for (;;) { // (every pass ends a sample of each lane in it: at most a block's samples)
             if (from_cache) {
                 const float4 c0 = *cache_slot(0), c1 = *cache_slot(1), c2 = *cache_slot(2);
@@ -1979,25 +2004,35 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 best.rec = __float_as_int(c2.x);
                 hit = best.geom >= 0;
                 cnt.rays += 1; // a path segment like any other, answered without a traversal (counted apart below)
-                shade_now = true;
+                settle_now = true;
             }
             {
                 const unsigned reused_now = (unsigned)__popcll(__ballot(from_cache));
                 cnt.reused += reused_now;
                 if (STATS && p.timeline) tl_count += reused_now; // (the launch timeline counts every path segment where it completes)
             }
-            if (__ballot(shade_now) == 0ull) break;
-            if (shade_now) {
+            if (__ballot(settle_now) == 0ull) break;
+            bool waiting = false;
+            if (settle_now) {
                 MaterialRef M;
                 M.global = BIG == 2 ? p.geoms + (hit ? best.geom : 0) : nullptr;
                 M.geom_base = L.geom_base;
                 M.g = best.geom;
-                active = shade_and_advance<EXTRAS>(p, best, hit, M, P);
+                const int r = settle_hit<EXTRAS>(p, best, hit, M, P);
                 inflight = false;
+                active = r != kPixelDone;
+                goes_on = r == kGoesOn;
+                waiting = r == kNewSample && cached; // a new sample of the same block, its primary hit parked
             }
-            const bool waiting = shade_now && active && P.b == 0 && cached; // a new sample of the same block, its primary hit parked
-            shade_now = false;
+            settle_now = false;
             from_cache = waiting && __popcll(__ballot(waiting)) >= p.reuse_quorum;
+        }
+        if (goes_on) {
+            MaterialRef M;
+            M.global = BIG == 2 ? p.geoms + best.geom : nullptr;
+            M.geom_base = L.geom_base;
+            M.g = best.geom;
+            scatter<EXTRAS>(p, best, M, P);
         }
         if (STATS) t2 = __builtin_amdgcn_s_memtime();
         {
