@@ -1269,7 +1269,11 @@ __device__ __forceinline__ void traverse_budget(const LDS& L, const TriRecord* _
                 }
             }
         } else {
-            while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
+            // A lane enters its next candidate mesh (object-space ray, slab constants: ~80 instructions) together with the lanes that
+            // start their query, at the top of a slice; in mid-slice, where one or two lanes at a time would ask for it, it waits for
+            // the next slice - unless no lane of the wave has anything else to traverse.
+            if (guard == 0 || budget <= 0 || __ballot(S.cur != kDone) == 0ull)
+                while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, wr, S);
         }
         if (STATS) tb = __builtin_amdgcn_s_memtime();
         if (__ballot(S.cur != kDone) == 0ull) break;
