@@ -162,11 +162,11 @@ int finalize_layout(FfState* s)
     s->stack_entries = depth4 + 1 + (s->top_depth > 0 ? s->top_depth + 1 : 0);
     if (!s->setup_threshold_forced) {
         // Traversal time slice, in inner-node rounds (trace_bvh_kernel): long enough for most queries of the scene's biggest
-        // tree to finish inside one slice.  Measured best on one MI355X: 6-8 for C2 (1 000 nodes, 4.4 visits per ray), 14-20
-        // for the 983 040-triangle sphere (180 000 nodes, 12.8 visits); both sit on 2 log4(nodes) - 4.
+        // tree to finish inside one slice.  Measured best on one MI355X (round 3's kernel, profiles/r03_r_slice_sweep.txt): 7 for C2
+        // (1 200 nodes), 12 for the 983 040-triangle sphere (180 000 nodes); both sit on 1.5 log4(nodes) - 0.7.
         int biggest = 1;
         for (size_t i = 0; i < s->slots.size(); ++i) biggest = std::max(biggest, s->slots[i].node4_count);
-        s->setup_threshold = std::max(4, std::min(24, (int)std::lround(2.0 * std::log((double)biggest) / std::log(4.0) - 3.9)));
+        s->setup_threshold = std::max(4, std::min(24, (int)std::lround(1.5 * std::log((double)biggest) / std::log(4.0) - 0.7)));
         s->setup_threshold = std::min(32, s->setup_threshold + 2 * s->top_depth); // big scenes: plus the walk through the geometry tree
     }
     s->scene_block_threads = bvh_block_threads(s, s->block_threads);

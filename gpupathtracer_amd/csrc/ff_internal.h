@@ -106,7 +106,8 @@ struct Wall {
     float cu, hu; // centre and half extent along the first of the other two axes (x: y, y: z, z: x)
     float cv, hv; // ... and along the second (x: z, y: x, z: y)
     int geom;     // record index of the plane
-    int pad[2];
+    int hi_geom1; // != 0: the entry holds two walls with this rectangle - this one at c and record hi_geom1 - 1 at hi_c > c
+    float hi_c;
 };
 static_assert(sizeof(Wall) == 32, "32-byte wall");
 struct WallTable {

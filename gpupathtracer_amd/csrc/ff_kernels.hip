@@ -719,6 +719,31 @@ __device__ __forceinline__ void wall_test(const Wall& w, float ixk, float oxk, f
     best_g = nearer ? w.geom : best_g;
 }
 
+// An entry that holds two walls with one rectangle, at w.c < w.hi_c (floor and ceiling, left and right wall of a box).  A ray
+// that starts between them can reach only the one its direction points at: the rectangle is tested once, at that wall's parameter;
+// the other wall is a certain miss when its own parameter is certainly negative (the same criterion as above) and goes to the
+// per-lane screen otherwise (an origin outside the pair, or on the wall itself).
+__device__ __forceinline__ void wall_test_pair(const Wall& w, float ixk, float oxk, float ou, float du, float ov, float dv, float dl, float tt, bool steep,
+                                               float wlen, float& best_d, int& best_g, bool& tie, unsigned& slow)
+{
+    const float tlo = __builtin_fmaf(w.c, ixk, oxk), thi = __builtin_fmaf(w.hi_c, ixk, oxk);
+    const bool up = ixk > 0.0f;
+    const float t = up ? thi : tlo, tother = up ? tlo : thi;
+    const int g = up ? w.hi_geom1 - 1 : w.geom, gother = up ? w.geom : w.hi_geom1 - 1;
+    slow |= !(tother < -tt) ? 1u << gother : 0u;
+    const float pu = __builtin_fmaf(t, du, ou), pv = __builtin_fmaf(t, dv, ov);
+    const float m = fmaxf(fabsf(pu - w.cu) - w.hu, fabsf(pv - w.cv) - w.hv);
+    const bool hit = m <= -dl && t > tt && steep;
+    const bool miss = m > dl || t < -tt;
+    slow |= (!hit && !miss) ? 1u << g : 0u;
+    const float d = t * wlen;
+    const bool nearer = hit && best_d > __builtin_fmaf(d, 1.0f + kRel, kAbs);
+    const bool farther = d > __builtin_fmaf(best_d, 1.0f + kRel, kAbs);
+    tie = tie || (hit && !nearer && !farther);
+    best_d = nearer ? d : best_d;
+    best_g = nearer ? g : best_g;
+}
+
 // All walls of the table against the calling lanes' rays (wave-uniform loops; the table comes through scalar loads).  Must run
 // on a query that holds nothing yet (begin_segment).  A lane that met a near tie between two walls gives all of them to the
 // per-lane screens, which rank on exact distances.
@@ -745,7 +770,8 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
         const bool steep = ax >= gmin;
         for (; i < nx; ++i) {
             const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
-            wall_test(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            if (cur.hi_geom1) wall_test_pair(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            else wall_test(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow);
             cur = nxt;
         }
     }
@@ -754,7 +780,8 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
         const bool steep = ay >= gmin;
         for (; i < ny; ++i) {
             const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
-            wall_test(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            if (cur.hi_geom1) wall_test_pair(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            else wall_test(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow);
             cur = nxt;
         }
     }
@@ -763,7 +790,8 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
         const bool steep = az >= gmin;
         for (; i < nz; ++i) {
             const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
-            wall_test(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            if (cur.hi_geom1) wall_test_pair(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            else wall_test(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow);
             cur = nxt;
         }
     }

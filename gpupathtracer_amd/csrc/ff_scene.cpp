@@ -548,14 +548,35 @@ void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out)
         ratio = std::max(ratio, smax / smin);
         scale_s = std::max(scale_s, smax + std::fabs(T[0]) + std::fabs(T[1]) + std::fabs(T[2]));
     }
+    // Two walls normal to the same axis with the same rectangle (floor and ceiling, left and right wall of a box) share one entry:
+    // a ray between them can reach only the one its direction points at, so the kernel computes both parameters, tests the
+    // rectangle once and hands the other wall to the per-lane screens unless its parameter is certainly negative (wall_test_pair).
+    const bool pairing = std::getenv("FF_NO_WALL_PAIRS") == nullptr;
+    std::vector<char> used(found.size(), 0);
     int n = 0;
     for (int axis = 0; axis < 3; ++axis)
-        for (const Found& f : found)
-            if (f.axis == axis) {
-                out.w[n++] = f.w;
-                out.count[axis] += 1;
-                out.mask |= 1u << f.w.geom;
+        for (size_t i = 0; i < found.size(); ++i) {
+            if (found[i].axis != axis || used[i]) continue;
+            used[i] = 1;
+            Wall w = found[i].w;
+            out.mask |= 1u << w.geom;
+            for (size_t j = i + 1; pairing && j < found.size(); ++j) {
+                const Wall& o = found[j].w;
+                if (found[j].axis != axis || used[j] || o.c == w.c) continue;
+                if (std::memcmp(&o.cu, &w.cu, 4 * sizeof(float)) != 0) continue; // cu, hu, cv, hv bit for bit
+                used[j] = 1;
+                out.mask |= 1u << o.geom;
+                const Wall& lo = o.c < w.c ? o : w;
+                const Wall& hi = o.c < w.c ? w : o;
+                Wall both = lo;
+                both.hi_geom1 = hi.geom + 1;
+                both.hi_c = hi.c;
+                w = both;
+                break;
             }
+            out.w[n++] = w;
+            out.count[axis] += 1;
+        }
     // margins: both scale with the anisotropy of the walls (a rounding error of the object-space test along a short axis is that
     // much larger in world units along a long one)
     out.margin_s = ratio * scale_s;
@@ -880,14 +901,30 @@ extern "C" int ff_debug_wall_table(const FfGeometry* host_geometries, int n, flo
     int count = 0, i = 0;
     for (int axis = 0; axis < 3; ++axis)
         for (int k = 0; k < t.count[axis]; ++k, ++i) {
-            if (out_walls7 && count < max_walls) {
-                const Wall& w = t.w[i];
-                float* o = out_walls7 + (size_t)count * 7;
-                o[0] = (float)cs.geoms[w.geom].orig_index;
-                o[1] = (float)axis;
-                o[2] = w.c; o[3] = w.cu; o[4] = w.hu; o[5] = w.cv; o[6] = w.hv;
+            const Wall& w = t.w[i];
+            for (int side = 0; side < (w.hi_geom1 ? 2 : 1); ++side) { // (an entry that holds two walls: the lower one first)
+                if (out_walls7 && count < max_walls) {
+                    float* o = out_walls7 + (size_t)count * 7;
+                    o[0] = (float)cs.geoms[side ? w.hi_geom1 - 1 : w.geom].orig_index;
+                    o[1] = (float)axis;
+                    o[2] = side ? w.hi_c : w.c; o[3] = w.cu; o[4] = w.hu; o[5] = w.cv; o[6] = w.hv;
+                }
+                ++count;
             }
-            ++count;
         }
     return count;
+}
+
+extern "C" int ff_debug_wall_entries(const FfGeometry* host_geometries, int n)
+{
+    using namespace ff;
+    clear_error();
+    CompiledScene cs;
+    const int st = compile_scene(host_geometries, n, default_bvh_params(), cs, /*build_bvh=*/false);
+    if (st != FF_OK) return -st;
+    int num_quads = 0;
+    for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
+    WallTable t;
+    build_wall_table(cs.geoms.data(), num_quads, t);
+    return t.count[0] + t.count[1] + t.count[2];
 }

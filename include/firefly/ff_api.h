@@ -136,6 +136,9 @@ FF_API int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneInfo* 
  * scene's first 32 planes) or minus an FfStatus.  Results never depend on the table: a plane it leaves out, and every hit inside
  * its margins, goes through the exact reference test.  Needs no GPU. */
 FF_API int ff_debug_wall_table(const FfGeometry* host_geometries, int n, float* out_walls7, int max_walls);
+/* ... and the number of ENTRIES of that table: two walls normal to the same axis with the same rectangle (floor and ceiling of a box)
+ * share one, so this is at most the count above.  Needs no GPU. */
+FF_API int ff_debug_wall_entries(const FfGeometry* host_geometries, int n);
 
 /* ---- rendering (kernel.cu:335-344 + launchPathTrace kernel.cu:218-221) -------------------------- */
 

@@ -551,3 +551,29 @@ def test_last_bounce_queries_end_after_the_planes_when_no_emitter_is_held(tracer
     tracer.upload_scene(scenes.cornell_wahoo_scene())
     tracer.render(cam, lib.render_params(96, 64, 1, 1, 0, T.TRACE_BVH, T.SHADE_NORMAL_DEBUG))
     assert tracer.stats().rays_cut_short == 0
+
+
+def test_wall_pairs_and_wall_table_do_not_change_a_bit(monkeypatch):
+    """Floor and ceiling, left and right wall of the box share one entry of the wall table (csrc/ff_scene.cpp build_wall_table,
+    csrc/ff_kernels.hip wall_test_pair): with pairs, without them (FF_NO_WALL_PAIRS=1) and without the table (FF_NO_WALL_TABLE=1;
+    both read at upload) the frame is the same, from inside the box, from outside it (origins beyond the pair: the other wall
+    goes to the exact per-lane screen) and from a camera ON the floor plane."""
+    scene = scenes.cornell_wahoo_scene()
+    cams = [scenes.posed_camera(80, 48, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0),
+            scenes.posed_camera(80, 48, position=(0.3, 6.0, 9.0), yaw=-92.0, pitch=-30.0),   # above the ceiling's plane, outside
+            scenes.posed_camera(80, 48, position=(-6.0, -1.0, 1.0), yaw=-10.0, pitch=5.0),   # left of the left wall
+            scenes.posed_camera(80, 48, position=(0.5, -2.5, 2.0), yaw=-95.0, pitch=10.0)]    # on the floor's plane
+    params = lib.render_params(80, 48, 5, 6, 9)
+    frames = {}
+    for knob in (None, "FF_NO_WALL_PAIRS", "FF_NO_WALL_TABLE"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        with lib.Tracer(0) as t:
+            t.upload_scene(scene)
+            frames[knob] = [t.render(cam, params)[1].copy() for cam in cams]
+        if knob:
+            monkeypatch.delenv(knob)
+    for knob in ("FF_NO_WALL_PAIRS", "FF_NO_WALL_TABLE"):
+        for a, b in zip(frames[None], frames[knob]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), knob
+    assert frames[None][0].max() > 0

@@ -203,6 +203,7 @@ def test_wall_table_takes_axis_aligned_planes_only(ff):
 
     box = scenes.cornell_wahoo_scene()
     w = table(box)
+    w_box = w.copy()
     planes = [i for i, s in enumerate(box._specs) if s[0] == T.GEOM_PLANE]
     assert sorted(w[:, 0].astype(int).tolist()) == planes
     assert w[:, 1].astype(int).tolist() == [0, 0, 1, 1, 1, 2]  # left / right, floor / ceiling / light, back
@@ -223,3 +224,12 @@ def test_wall_table_takes_axis_aligned_planes_only(ff):
     # object z (the quad's normal) ends up along one world axis; the quad's 2 x 6 rectangle along the two others
     assert int(w[0, 1]) in (0, 1, 2) and sorted(np.round(w[0, [4, 6]], 4).tolist()) == [1.0, 3.0]
     assert lib.ff_debug_wall_table(None, 0, None, 0) < 0
+    # floor / ceiling and left / right wall have the same rectangles: one entry per pair (the kernel tests the rectangle once, at the
+    # wall the ray points at); the light under the ceiling and the back wall stay single
+    assert lib.ff_debug_wall_entries(box.geometries, len(box)) == 4
+    os.environ["FF_NO_WALL_PAIRS"] = "1"
+    try:
+        assert lib.ff_debug_wall_entries(box.geometries, len(box)) == 6
+        assert np.array_equal(table(box), w_box)
+    finally:
+        del os.environ["FF_NO_WALL_PAIRS"]
