@@ -105,7 +105,7 @@ constexpr int kRaySlots = 30, kRaySlotFirst = 2, kRaySlotStride = 16;
 // ... and next to each ray slot the count of those rays that were answered without a traversal: counters[kAnsweredWord + kRaySlotStride * j]
 constexpr int kAnsweredWord = kRaySlotStride * kRaySlotFirst + 1;
 constexpr int kCutShortWord = kRaySlotStride * kRaySlotFirst + 3;     // (+ kRaySlotStride * j) last-bounce queries that ended after the analytic records
-constexpr int kCulledPixelsWord = kRaySlotStride * kRaySlotFirst + 2; // cull_mask_kernel: pixels whose items the queue drops
+constexpr int kCulledPixelsWord = kRaySlotStride * kRaySlotFirst + 2; // (+ kRaySlotStride * j) cull_mask_kernel: pixels whose items the queue drops
 constexpr int kCounterWords = 512; // 64-bit words of the counter block (4 KiB; the work-queue counters follow)
 constexpr int kTimelineBuckets = 1024;
 // Work queue: up to kQueueCounters counters, 4 KiB apart so that they sit in different memory channels (atomics on one address

@@ -2228,7 +2228,9 @@ __global__ void cull_mask_kernel(const KParams p, unsigned long long* mask)
     const unsigned long long word = __ballot(culled);
     if ((threadIdx.x & 63) == 0 && pitem < ((p.pix_items + 63u) & ~63u)) {
         mask[pitem >> 6] = word;
-        if (word) atomicAdd(&p.counters[kCulledPixelsWord], (unsigned long long)__popcll(word)); // (the host turns pixels into rays)
+        // (the host adds the slots and turns pixels into rays; on ONE address the 32 000 atomics of a 1080p frame queue up for
+        // 0.3 ms - five times the reference's whole 1-spp frame)
+        if (word) atomicAdd(&p.counters[kCulledPixelsWord + kRaySlotStride * ((pitem >> 6) % kRaySlots)], (unsigned long long)__popcll(word));
     }
 }
 

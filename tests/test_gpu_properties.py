@@ -454,6 +454,11 @@ def test_primary_rays_that_miss_the_scene_box_are_dropped_at_the_queue(tracer, m
         for params in (lib.render_params(w, h, 6, 5, 3), lib.render_params(w, h, 3, 130, 4), lib.render_params(w, h, 1, 1, shade_mode=T.SHADE_NORMAL_DEBUG)):
             bvh = tracer.render(cam, params)
             rays = tracer.stats().rays_traced
+            st = tracer.stats()
+            assert st.rays_answered <= rays
+            if st.flags & T.FF_STATS_TAIL_ITEMS and params.spp <= 64:
+                # the frame's only block went out sample by sample: nothing to drop, no mask pass; only repeated primaries count
+                assert st.rays_answered <= w * h * (params.spp - 1)
             assert (bvh[1] == 0).all(axis=2).mean() > 0.5  # most of the frame is background
             params.trace_mode = T.TRACE_BRUTE_FORCE
             brute = tracer.render(cam, params)

@@ -16,7 +16,7 @@ stats() {  # name, bench args...
 stats c2 --steps 3 --warmup 1
 tools/pmc_passes.sh "$OUT/pmc_c2" "sq1 sq2 sq3 sqc tcp tcc1 tcc2 grbm" --steps 1 --warmup 1 --no-companion
 python3 tools/pmc_summary.py "$OUT/pmc_c2" > "$OUT/${TAG}_c2_pmc_summary.txt"
-python3 tools/pmc_to_json.py "$OUT/pmc_c2" "$OUT/${TAG}_c2_pmc.json" "round 3 kernel (wall table, least-area 4-wide collapse, stack spill)"
+python3 tools/pmc_to_json.py "$OUT/pmc_c2" "$OUT/${TAG}_c2_pmc.json" "round 3 kernel (wall table with pairs, least-area 4-wide collapse, stack spill, primary-hit reuse, two-step shading, last-bounce cut)"
 rm -rf "$OUT"/pmc_c2/*/
 stats c4 --scene c4 --steps 3 --warmup 1
 tools/pmc_passes.sh "$OUT/pmc_c4" "sq1 sq2 sq3 tcp tcc1 tcc2 grbm" --scene c4 --steps 1 --warmup 1 --no-companion
