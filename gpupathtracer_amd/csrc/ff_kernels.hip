@@ -854,10 +854,14 @@ __device__ __forceinline__ bool scan_records(const LDS& L, const WallTable& W, c
     const float limit = fminf(S.best.dist, S.pend.dist);
     {
         // (the boxes of the meshes that have a tree come with the table: scalar loads, the next one requested before the test)
-        WallTable::MeshBox cur = W.box[0];
+        // (one 32-byte scalar load per box: read field by field the compiler issues seven loads and as many address computations)
+        typedef unsigned box_words __attribute__((ext_vector_type(8)));
+        static_assert(sizeof(WallTable::MeshBox) == 32, "one box, one load");
+        box_words cur = *reinterpret_cast<const box_words*>(&W.box[0]);
         for (int i = 0; i < W.num_boxes; ++i) {
-            const WallTable::MeshBox nxt = W.box[min(i + 1, 31)];
-            S.meshes |= slab_may_hit(cur.mn[0], cur.mn[1], cur.mn[2], cur.mx[0], cur.mx[1], cur.mx[2], ws, limit) ? 1u << cur.geom : 0u;
+            const box_words nxt = *reinterpret_cast<const box_words*>(&W.box[min(i + 1, 31)]);
+            S.meshes |= slab_may_hit(__uint_as_float(cur.s0), __uint_as_float(cur.s1), __uint_as_float(cur.s2), __uint_as_float(cur.s4), __uint_as_float(cur.s5),
+                                     __uint_as_float(cur.s6), ws, limit) ? 1u << cur.s3 : 0u;
             cur = nxt;
         }
     }
