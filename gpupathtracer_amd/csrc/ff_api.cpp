@@ -762,6 +762,9 @@ int upload_with_device_builder(FfState* s, const FfGeometry* host_geometries, in
     FF_HIP(scene_alloc(s, (void**)&s->d_tris, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriRecord)));
     FF_HIP(scene_alloc(s, (void**)&s->d_normals, (cs.total_tris ? (size_t)cs.total_tris : 1) * sizeof(TriNormals)));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, (node_cap ? node_cap : 1) * sizeof(BvhNode)));
+    // (the kernels address a node by a 32-bit byte offset from the array's base)
+    if ((uint64_t)(node_cap + cs.geoms.size() + 1) * sizeof(Bvh4Node) >= (1ull << 32))
+        return fail(FF_ERR_UNSUPPORTED, "scene needs %llu 4-wide BVH nodes: more than the 38 million (4 GiB) the kernels address", (unsigned long long)(node_cap + cs.geoms.size() + 1));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (node_cap + cs.geoms.size() + 1) * sizeof(Bvh4Node))); // (+ the geometry tree of a big scene)
     FF_HIP(scene_alloc(s, (void**)&s->d_parent, (node_cap ? node_cap : 1) * sizeof(int)));
     FF_HIP(scene_alloc(s, (void**)&s->d_role, node_cap ? node_cap : 1));
@@ -887,6 +890,9 @@ int upload_compiled(FfState* s, const CompiledScene& cs)
     static_assert(sizeof(TriNormals) == sizeof(TriRecord), "parallel arrays of equal stride");
     if (!cs.normals.empty()) FF_HIP(hipMemcpy(s->d_normals, cs.normals.data(), cs.normals.size() * sizeof(TriNormals), hipMemcpyHostToDevice));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes, node_bytes));
+    // (the kernels address a node by a 32-bit byte offset from the array's base)
+    if ((uint64_t)(cs.nodes.size() + cs.geoms.size() + 1) * sizeof(Bvh4Node) >= (1ull << 32))
+        return fail(FF_ERR_UNSUPPORTED, "scene needs %llu 4-wide BVH nodes: more than the 38 million (4 GiB) the kernels address", (unsigned long long)(cs.nodes.size() + cs.geoms.size() + 1));
     FF_HIP(scene_alloc(s, (void**)&s->d_nodes4, (cs.nodes.size() + cs.geoms.size() + 1) * sizeof(Bvh4Node))); // (+ the geometry tree of a big scene)
     FF_HIP(scene_alloc(s, (void**)&s->d_parent, (cs.nodes.size() ? cs.nodes.size() : 1) * sizeof(int)));
     FF_HIP(scene_alloc(s, (void**)&s->d_role, cs.nodes.size() ? cs.nodes.size() : 1));

@@ -971,7 +971,7 @@ __device__ __forceinline__ void pop_entry(const LDS& L, const uint4* __restrict_
             lk = ff_smem[S.lds_first + node + 6 * L.node_cap];
             FF_PIN4(lk);
         } else {
-            lk = nodes4[(size_t)(S.node_base + node) * kNodeVec4 + 6];
+            lk = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes4) + ((unsigned)(S.node_base + node) * (unsigned)(kNodeVec4 * 16) + 96u));
             FF_PIN4(lk);
         }
         S.cur = select_slot(lk, (e >> 2) & 3);
@@ -1120,15 +1120,23 @@ __device__ __forceinline__ void inner_step(const LDS& L, const uint4* __restrict
         lk = *reinterpret_cast<const uint4*>(nb + 6 * 16 * L.node_cap);
         FF_PIN4(lk);
     } else {
-        const uint4* p = nodes4 + (size_t)(S.node_base + rel) * kNodeVec4;
-        const int gx = S.ix < 0.0f ? 3 : 0, gy = S.iy < 0.0f ? 4 : 1, gz = S.iz < 0.0f ? 5 : 2; // (set_box_planes)
-        nx = p[gx];
-        ny = p[gy];
-        nz = p[gz];
-        fx = p[3 - gx];
-        fy = p[5 - gy];
-        fz = p[7 - gz];
-        lk = p[6];
+        // (32-bit byte offsets from the array's base - a node index has 22 bits, kPackedEntry - so that the seven loads take the
+        // base from a scalar register pair and one add each, instead of 64-bit address arithmetic per quarter)
+        const char* const base = reinterpret_cast<const char*>(nodes4);
+        static_assert(kNodeVec4 * 16 == 112, "node size");
+        // (x 112 as two shifts: the compiler folds them back into the quarter-rate 32-bit multiply unless one is hidden from it)
+        const unsigned ni = (unsigned)(S.node_base + rel);
+        unsigned nb = ni << 7;
+        asm volatile("" : "+v"(nb));
+        nb -= ni << 4;
+        const unsigned gx = S.ix < 0.0f ? 48u : 0u, gy = S.iy < 0.0f ? 64u : 16u, gz = S.iz < 0.0f ? 80u : 32u; // (set_box_planes)
+        nx = *reinterpret_cast<const uint4*>(base + (nb + gx));
+        ny = *reinterpret_cast<const uint4*>(base + (nb + gy));
+        nz = *reinterpret_cast<const uint4*>(base + (nb + gz));
+        fx = *reinterpret_cast<const uint4*>(base + (nb + (48u - gx)));
+        fy = *reinterpret_cast<const uint4*>(base + (nb + (80u - gy)));
+        fz = *reinterpret_cast<const uint4*>(base + (nb + (112u - gz)));
+        lk = *reinterpret_cast<const uint4*>(base + (nb + 96u));
         FF_PIN4(lk);
     }
     if (STATS) { cnt.nodes += 1; probe_round(cnt.inner_rounds); }
