@@ -1926,6 +1926,16 @@ __device__ __forceinline__ void init_path(Path& P)
 // traversal state in registers and in their LDS stack and simply continue in the next iteration: per-ray traversal cost is
 // heavy-tailed, and run to completion the inner-node phase had 11 % of its lanes busy.  Latency is hidden by occupancy: 1024
 // threads per workgroup = 4 waves per SIMD.
+//
+// One iteration, in order (each a pass the whole wave walks through, whatever the number of lanes in it - which is why the
+// expensive ones run once per iteration and the cheap one as often as needed):
+//   finish_segment  exact evaluation of the finished queries' winners (kernel.cu:110-125)
+//   settle_hit      does the path end here?  radiance, next sample, end of block; repeated for the lanes whose next sample starts
+//                   from the block's parked primary hit (every sample of a pixel starts with the same ray)
+//   scatter         normal, random numbers, next ray: once, for paths that go on from a traced hit and from a parked hit alike
+//   acquire_pixel   new (pixel, sample block) items for the lanes without work
+//   begin_segment   walls (wall table), other planes / spheres, candidate meshes; a last-bounce query that holds no emitter ends here
+//   traverse_budget one time slice of the 4-wide trees (a lane enters its next candidate mesh at the top of a slice)
 
 // EXTRAS = false is the instantiation for scenes made of what the reference itself renders (planes and meshes, diffuse
 // and emitting surfaces): the plane/sphere boundary becomes a compile-time "never" and the MIRROR / GLASS branches of the
