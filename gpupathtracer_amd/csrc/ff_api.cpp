@@ -146,7 +146,7 @@ int finalize_layout(FfState* s)
     if (s->num_geoms > kChunkGeometries) {
         std::vector<BvhNode> top2;
         std::vector<Bvh4Node> top4;
-        s->num_scan = std::getenv("FF_NO_SCAN_PLANES") ? 0 : count_scan_planes(s->h_geoms, s->num_quads);
+        s->num_scan = s->sw.no_scan_planes ? 0 : count_scan_planes(s->h_geoms, s->num_quads);
         build_geometry_tree(s->h_geoms, top2, s->num_scan);
         s->top_depth = collapse_geometry_tree(top2, top4);
         s->top_count = (int)top4.size();
@@ -155,7 +155,7 @@ int finalize_layout(FfState* s)
         FF_HIP(hipStreamSynchronize(s->stream)); // (`top4` goes out of scope)
     }
     // the axis-aligned walls among the planes every query screens (all planes of a small scene, the leading num_scan of a big one)
-    build_wall_table(s->h_geoms.data(), std::getenv("FF_NO_WALL_TABLE") ? 0 : (s->num_geoms > kChunkGeometries ? s->num_scan : s->num_quads), s->walls);
+    build_wall_table(s->h_geoms.data(), s->sw.no_wall_table ? 0 : (s->num_geoms > kChunkGeometries ? s->num_scan : s->num_quads), s->walls, !s->sw.no_wall_pairs);
     if (s->num_geoms <= kChunkGeometries) add_mesh_boxes(s->h_geoms.data(), s->num_planes, s->num_geoms, s->walls);
     // one entry per visited node above the cursor (inner_step) plus a spare; in big scenes the pending entries of the
     // geometry tree sit below a mesh's own
@@ -180,7 +180,7 @@ int finalize_layout(FfState* s)
     // whole stack in LDS.
     constexpr int kMinLdsStack = 4;
     s->stack_lds_levels = s->stack_entries;
-    if (s->scene_block_threads > 0 && !std::getenv("FF_NO_STACK_SPILL")) {
+    if (s->scene_block_threads > 0 && !s->sw.no_stack_spill) {
         const int want = nodes4 + s->top_count;
         if (want > max_lds_nodes(s->stack_entries, block, lds_records(s))) {
             int levels = s->stack_entries;
@@ -340,9 +340,9 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             return fail(FF_ERR_UNSUPPORTED, "4-wide BVH of depth %d does not fit the LDS traversal stack (512 threads x %d levels + %d geometry records > 160 KiB); "
                         "upload with FF_BUILD_HOST_SAH or render with FF_TRACE_BRUTE_FORCE", s->max_depth4, s->max_depth4 + 1, s->num_geoms);
     }
-    if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) {
-        unsigned long words = 0, pattern = 0;
-        if (std::sscanf(e, "%lu,%lx", &words, &pattern) == 2 && prm->trace_mode == FF_TRACE_BVH) {
+    if (s->sw.lds_fill) {
+        const unsigned long words = s->sw.lds_fill_words, pattern = s->sw.lds_fill_pattern;
+        if (prm->trace_mode == FF_TRACE_BVH) {
             const size_t bytes = bvh_lds_bytes(s->lds_cap, s->stack_lds_levels, block_threads, lds_records(s));
             k.debug_lds_words = (unsigned)std::min<size_t>(words, bytes / 4);
             k.debug_lds_pattern = (unsigned)pattern;
@@ -358,7 +358,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.walls = s->walls;
     k.emitter_mask = 0u;
     k.cut_last = 0;
-    if (prm->trace_mode == FF_TRACE_BVH && !debug && !std::getenv("FF_NO_LAST_BOUNCE_CUT")) {
+    if (prm->trace_mode == FF_TRACE_BVH && !debug && !s->sw.no_last_bounce_cut) {
         // The last segment of a path adds radiance only when it ends on an emitter.  If every emitter is one of the analytic records
         // all queries screen before anything else (all planes and spheres of a small scene, the scan planes of a big one), a
         // last-bounce query that holds no emitter after that screening is over (scan_records).
@@ -390,7 +390,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             valid = valid && mn[a] <= mx[a] && std::fabs(mn[a]) < 1e30f && std::fabs(mx[a]) < 1e30f;
             outside = outside || !(cp[a] >= mn[a] && cp[a] <= mx[a]);
         }
-        cull = prm->trace_mode == FF_TRACE_BVH && valid && outside && !std::getenv("FF_NO_PRIMARY_CULL");
+        cull = prm->trace_mode == FF_TRACE_BVH && valid && outside && !s->sw.no_primary_cull;
     }
     k.rgb8 = rgb8_dev;
     k.radiance = radiance_dev;
@@ -412,9 +412,8 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
     k.primary_cache = nullptr;
-    k.reuse_quorum = 1;
-    if (const char* e = std::getenv("FF_REUSE_QUORUM")) k.reuse_quorum = std::max(1, std::min(65, std::atoi(e)));
-    if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !std::getenv("FF_NO_PRIMARY_REUSE")) {
+    k.reuse_quorum = s->sw.reuse_quorum;
+    if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !s->sw.no_primary_reuse) {
         // one slot per thread of the launch for the closest hit of its sample block's primary ray (trace_bvh_kernel)
         const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)grid * (size_t)block_threads * sizeof(float4));
         if (cst != FF_OK) return cst;
@@ -444,9 +443,9 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         const int samples_per_item = std::max(1, std::min(k.block_spp, k.spp_total));
         // (the strips of a multi-GPU rank: 32; slowest of eight ranks 125.5 ms against 126.9 with 64 and 125.9 with 16)
         k.queue_chunk = samples_per_item >= 64 ? (num_parts > 1 ? 32u : 64u) : (unsigned)std::min(32, std::max(4, 64 / samples_per_item));
-        if (const char* e = std::getenv("FF_QUEUE_CHUNK")) k.queue_chunk = (unsigned)std::max(1, std::min(4096, std::atoi(e)));
+        if (s->sw.queue_chunk > 0) k.queue_chunk = (unsigned)s->sw.queue_chunk;
         k.queue_counters = std::min(kQueueCountersDefault, grid);
-        if (const char* e = std::getenv("FF_QUEUE_COUNTERS")) k.queue_counters = std::max(1, std::min(std::min(kQueueCounters, grid), std::atoi(e)));
+        if (s->sw.queue_counters > 0) k.queue_counters = std::min(std::min(kQueueCounters, grid), s->sw.queue_counters);
     }
     hipStream_t st = s->stream;
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced pixels read 0.  With the full grid the combine pass writes every pixel
@@ -588,6 +587,38 @@ int render_local(FfState* s, const FfCamera* camera, const FfRenderParams* prm, 
 
 extern "C" {
 
+namespace {
+// The experiment switches of FfState::Switches, from the environment (ff_create; ff_debug_reload_switches).
+void read_switches(FfState* s)
+{
+    FfState::Switches w;
+    w.no_last_bounce_cut = std::getenv("FF_NO_LAST_BOUNCE_CUT") != nullptr;
+    w.no_primary_cull = std::getenv("FF_NO_PRIMARY_CULL") != nullptr;
+    w.no_primary_reuse = std::getenv("FF_NO_PRIMARY_REUSE") != nullptr;
+    w.no_any_hit = std::getenv("FF_NO_ANY_HIT") != nullptr;
+    if (const char* e = std::getenv("FF_REUSE_QUORUM")) w.reuse_quorum = std::max(1, std::min(65, std::atoi(e)));
+    if (const char* e = std::getenv("FF_QUEUE_CHUNK")) w.queue_chunk = std::max(1, std::min(4096, std::atoi(e)));
+    if (const char* e = std::getenv("FF_QUEUE_COUNTERS")) w.queue_counters = std::max(1, std::min(kQueueCounters, std::atoi(e)));
+    w.no_wall_table = std::getenv("FF_NO_WALL_TABLE") != nullptr;
+    w.no_wall_pairs = std::getenv("FF_NO_WALL_PAIRS") != nullptr;
+    w.no_stack_spill = std::getenv("FF_NO_STACK_SPILL") != nullptr;
+    w.no_scan_planes = std::getenv("FF_NO_SCAN_PLANES") != nullptr;
+    if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) w.lds_fill = std::sscanf(e, "%lu,%lx", &w.lds_fill_words, &w.lds_fill_pattern) == 2;
+    if (const char* e = std::getenv("FF_POOL")) w.pool = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("FF_POOL_QUORUM")) w.pool_quorum = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_BATCH_MIN")) w.pool_batch_min = std::max(1, std::min(64, std::atoi(e)));
+    s->sw = w;
+}
+} // namespace
+
+int ff_debug_reload_switches(FfState* s)
+{
+    clear_error();
+    if (!s) return fail(FF_ERR_INVALID_ARG, "ff_debug_reload_switches: state is null");
+    read_switches(s);
+    return FF_OK;
+}
+
 int ff_create(FfState** out_state, int device_id)
 {
     clear_error();
@@ -611,6 +642,7 @@ int ff_create(FfState** out_state, int device_id)
             s->block_threads = v;
         }
     }
+    read_switches(s);
     if (const char* e = std::getenv("FF_DEBUG_FAIL_ALLOC")) s->debug_fail_alloc = std::atoi(e);
     if (const char* e = std::getenv("FF_DEBUG_TIMELINE_US")) s->timeline_bucket_us = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("FF_TAIL_MIN_BLOCKS")) s->tail_min_blocks = std::max(1, std::atoi(e));

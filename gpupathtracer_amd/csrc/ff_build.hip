@@ -186,7 +186,15 @@ __device__ __forceinline__ void coherent_store(float* p, float v)
 // before my arrival counts" / "my loads start after it": release_arrival() / acquire_arrival().  A __threadfence() would also
 // write back and invalidate the XCD's whole L2 (the L2s of the eight XCDs are not coherent with each other for ordinary
 // accesses), thousands of times per launch: the 983 040-triangle treelet pass took 12 ms with it and 3 ms without.
-__device__ __forceinline__ void release_arrival() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// The workgroup-scope fence only stops the COMPILER from moving accesses across it (on gfx950 it emits no instruction); what makes
+// "my stores have completed" true in the binary is the explicit wait for the wave's outstanding vector-memory operations in front
+// of it: the sc1 stores above and the arrival atomic hit different lines and L2 channels and may otherwise complete out of order
+// (the Makefile's `check-arrivals` target greps the ISA for an sc1 store that reaches an arrival atomic without that wait).
+__device__ __forceinline__ void release_arrival()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
 __device__ __forceinline__ void acquire_arrival() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ int arrive(int* counter, int n = 1) { return __hip_atomic_fetch_add(counter, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

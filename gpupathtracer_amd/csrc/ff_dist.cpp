@@ -164,7 +164,10 @@ struct FfDistContext {
     bool self_loop = false; // FF_DIST_SELF_LOOP=1: rank 0 also moves its OWN strips through ncclSend/ncclRecv (a one-rank
                             // communicator then exercises the whole transport on a one-GPU box)
     bool broken = false;    // the transport failed or timed out: the communicator was aborted, ff_dist_init makes a new one
-    double timeout_s = 300.0; // FF_DIST_TIMEOUT_S: longest wait for the other ranks in one frame
+    double timeout_s = 300.0; // FF_DIST_TIMEOUT_S: longest wait for the OTHER ranks in one frame (the clock starts when this rank's own
+                              // strips have drained: a long frame is not a missing peer)
+    int fail_rank = -1;       // FF_DEBUG_DIST_FAIL_RANK (tests, read once at ff_dist_init): that rank reports an injected local failure
+    hipEvent_t ev_local = nullptr; // recorded behind this rank's own launches of a frame
     int* d_status = nullptr;  // [0] this rank's status of the frame, [1] the job's (all-reduce, maximum)
     int* h_status = nullptr;  // pinned mirror
     unsigned char* d_pack = nullptr; // this rank's packed strips (non-root ranks; rank 0 with self_loop)
@@ -180,20 +183,28 @@ namespace {
 // report the error and leave instead of sitting in a stream wait for ever.  A fresh process is the retry.
 void abandon_comm(FfDistContext* d)
 {
-    if (d->comm) {
-        if (g_rccl.CommAbort) (void)g_rccl.CommAbort(d->comm);
-        else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
-    }
+    // (without ncclCommAbort the handle is dropped, not destroyed: ncclCommDestroy waits for the pending operations, which is
+    // the wait this function exists to end)
+    if (d->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(d->comm);
     d->comm = nullptr;
     d->broken = true;
 }
 
 // hipStreamSynchronize with a deadline and an eye on the communicator: returns FF_ERR_COMM (communicator abandoned) when RCCL
-// reports an asynchronous error or the stream has not drained after timeout_s.
-int wait_stream(FfDistContext* d, int device, hipStream_t stream, const char* what)
+// reports an asynchronous error or the stream has not drained timeout_s after `local_done` (an event behind this rank's own
+// work on the stream; null: from now).  The deadline bounds the wait for the OTHER ranks: while this rank's own strips are
+// still rendering - 1080p at 400 000 spp takes minutes - nothing is late.
+int wait_stream(FfDistContext* d, int device, hipStream_t stream, const char* what, hipEvent_t local_done = nullptr)
 {
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
+    const auto t_begin = t0;
+    bool local_pending = local_done != nullptr;
     for (;;) {
+        if (local_pending) {
+            const hipError_t lq = hipEventQuery(local_done);
+            if (lq == hipErrorNotReady) t0 = std::chrono::steady_clock::now(); // own work still running: the clock has not started
+            else local_pending = false;                                        // (drained, or an error the stream query below reports)
+        }
         const hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) return FF_OK;
         if (q != hipErrorNotReady) {
@@ -213,7 +224,8 @@ int wait_stream(FfDistContext* d, int device, hipStream_t stream, const char* wh
             return fail(FF_ERR_COMM, "rank %d: %s did not complete within %.0f s (FF_DIST_TIMEOUT_S): a peer rank is missing or stuck; communicator aborted",
                         d->rank, what, d->timeout_s);
         }
-        if (waited > 200e-6) std::this_thread::sleep_for(std::chrono::microseconds(50)); // (a frame renders for milliseconds: do not burn a core on it)
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 200e-6)
+            std::this_thread::sleep_for(std::chrono::microseconds(50)); // (a frame renders for milliseconds: do not burn a core on it)
     }
 }
 
@@ -230,6 +242,7 @@ void dist_release(FfState* s)
     if (d->d_gather) (void)hipFree(d->d_gather);
     if (d->d_status) (void)hipFree(d->d_status);
     if (d->h_status) (void)hipHostFree(d->h_status);
+    if (d->ev_local) (void)hipEventDestroy(d->ev_local);
     delete d;
     s->dist = nullptr;
 }
@@ -280,8 +293,11 @@ int ff_dist_init(FfState* s, int rank, int world_size, const void* id, int bytes
     d->world = world_size;
     if (const char* e = std::getenv("FF_DIST_SELF_LOOP")) d->self_loop = std::atoi(e) != 0;
     if (const char* e = std::getenv("FF_DIST_TIMEOUT_S")) d->timeout_s = std::max(1.0, std::atof(e));
-    if (hipMalloc((void**)&d->d_status, 2 * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&d->h_status, 2 * sizeof(int)) != hipSuccess) {
+    if (const char* e = std::getenv("FF_DEBUG_DIST_FAIL_RANK")) d->fail_rank = std::atoi(e);
+    if (hipMalloc((void**)&d->d_status, 2 * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&d->h_status, 2 * sizeof(int)) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_local, hipEventDisableTiming) != hipSuccess) {
         if (d->d_status) (void)hipFree(d->d_status);
+        if (d->h_status) (void)hipHostFree(d->h_status);
         delete d;
         return fail(FF_ERR_OOM, "ff_dist_init: no memory for the status words");
     }
@@ -291,6 +307,7 @@ int ff_dist_init(FfState* s, int rank, int world_size, const void* id, int bytes
     if (r != ncclSuccess) {
         (void)hipFree(d->d_status);
         (void)hipHostFree(d->h_status);
+        (void)hipEventDestroy(d->ev_local);
         delete d;
         return fail(FF_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world_size, s->device, g_rccl.GetErrorString(r));
     }
@@ -304,6 +321,14 @@ int ff_dist_shutdown(FfState* s)
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_dist_shutdown: state is null");
     (void)hipSetDevice(s->device);
     dist_release(s);
+    return FF_OK;
+}
+
+int ff_debug_dist_fail_rank(FfState* s, int rank)
+{
+    clear_error();
+    if (!s || !s->dist) return fail(FF_ERR_INVALID_ARG, "ff_debug_dist_fail_rank: call ff_dist_init first");
+    s->dist->fail_rank = rank;
     return FF_OK;
 }
 
@@ -355,8 +380,7 @@ int ff_render_distributed(FfState* s, const FfCamera* camera, const FfRenderPara
     RootOutputs out;
     unsigned char* pack = nullptr;
     int local = check_render_call(s, camera, params, "ff_render_distributed");
-    if (const char* e = std::getenv("FF_DEBUG_DIST_FAIL_RANK")) // tests: that rank reports an injected local failure
-        if (local == FF_OK && std::atoi(e) == rank) local = fail(FF_ERR_OOM, "injected failure on rank %d (FF_DEBUG_DIST_FAIL_RANK)", rank);
+    if (local == FF_OK && d->fail_rank == rank) local = fail(FF_ERR_OOM, "injected failure on rank %d (FF_DEBUG_DIST_FAIL_RANK)", rank);
     if (local == FF_OK) {
         if (strip_rows <= 0) strip_rows = default_strip_rows(world);
         L.width = params->width;
@@ -382,7 +406,8 @@ int ff_render_distributed(FfState* s, const FfCamera* camera, const FfRenderPara
     if (world > 1 || loop_back) {
         d->h_status[0] = local == FF_OK ? 0 : 1;
         d->h_status[1] = -1;
-        hipError_t e = hipMemcpyAsync(d->d_status, d->h_status, sizeof(int), hipMemcpyHostToDevice, s->stream);
+        hipError_t e = hipEventRecord(d->ev_local, s->stream); // behind this rank's strips: the deadline of the wait below starts there
+        if (e == hipSuccess) e = hipMemcpyAsync(d->d_status, d->h_status, sizeof(int), hipMemcpyHostToDevice, s->stream);
         ncclResult_t r = ncclSuccess;
         if (e == hipSuccess) r = g_rccl.AllReduce(d->d_status, d->d_status + 1, 1, ncclInt32, ncclMax, d->comm, s->stream);
         if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(d->h_status + 1, d->d_status + 1, sizeof(int), hipMemcpyDeviceToHost, s->stream);
@@ -391,7 +416,7 @@ int ff_render_distributed(FfState* s, const FfCamera* camera, const FfRenderPara
             abandon_comm(d);
             return fail(FF_ERR_COMM, "rank %d could not post its frame status: %s", rank, e != hipSuccess ? hipGetErrorString(e) : g_rccl.GetErrorString(r));
         }
-        const int wst = wait_stream(d, s->device, s->stream, "the ranks' status agreement");
+        const int wst = wait_stream(d, s->device, s->stream, "the ranks' status agreement", d->ev_local);
         if (wst != FF_OK) return wst;
         if (d->h_status[1] != 0 && local == FF_OK) verdict = FF_ERR_COMM;
     }

@@ -130,7 +130,7 @@ struct WallTable {
 // columns of its model matrix are parallel to three different world axes to within 2e-7 of their lengths (rotations by multiples
 // of 90 degrees come out of glm's cos/sin that exact), its normal is the unit quad's (0, 0, 1) and its scales differ by at most a
 // factor of 16.  At most kMaxWalls planes, the leading (largest) ones.
-void build_wall_table(const struct GeomRecord* geoms, int limit, WallTable& out);
+void build_wall_table(const struct GeomRecord* geoms, int limit, WallTable& out, bool pairing = true); // pairing: walls that share a rectangle share an entry
 // ... and the mesh boxes of a small scene (records [first, n), n <= 32).
 void add_mesh_boxes(const struct GeomRecord* geoms, int first, int n, WallTable& out);
 

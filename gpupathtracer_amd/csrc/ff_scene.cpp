@@ -502,7 +502,7 @@ int count_scan_planes(const std::vector<GeomRecord>& geoms, int num_quads)
     return n;
 }
 
-void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out)
+void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out, bool pairing)
 {
     std::memset(&out, 0, sizeof out);
     struct Found {
@@ -551,7 +551,6 @@ void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out)
     // Two walls normal to the same axis with the same rectangle (floor and ceiling, left and right wall of a box) share one entry:
     // a ray between them can reach only the one its direction points at, so the kernel computes both parameters, tests the
     // rectangle once and hands the other wall to the per-lane screens unless its parameter is certainly negative (wall_test_pair).
-    const bool pairing = std::getenv("FF_NO_WALL_PAIRS") == nullptr;
     std::vector<char> used(found.size(), 0);
     int n = 0;
     for (int axis = 0; axis < 3; ++axis)
@@ -897,7 +896,7 @@ extern "C" int ff_debug_wall_table(const FfGeometry* host_geometries, int n, flo
     int num_quads = 0;
     for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
     WallTable t;
-    build_wall_table(cs.geoms.data(), num_quads, t);
+    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr); // (stateless test helper: the environment decides)
     int count = 0, i = 0;
     for (int axis = 0; axis < 3; ++axis)
         for (int k = 0; k < t.count[axis]; ++k, ++i) {
@@ -925,6 +924,6 @@ extern "C" int ff_debug_wall_entries(const FfGeometry* host_geometries, int n)
     int num_quads = 0;
     for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
     WallTable t;
-    build_wall_table(cs.geoms.data(), num_quads, t);
+    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr); // (stateless test helper: the environment decides)
     return t.count[0] + t.count[1] + t.count[2];
 }

@@ -87,6 +87,21 @@ struct FfState {
     unsigned long long* h_counters = nullptr;  // pinned mirror for the per-frame read-back
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool collect_stats = false;
+    // Experiment switches (DESIGN.md "knobs"): read from the environment ONCE, at ff_create (ff_debug_reload_switches re-reads them on
+    // request: the A/B tests); the render and layout paths only look here, so a state behaves the same from frame to frame and no
+    // getenv runs next to another thread's setenv.
+    struct Switches {
+        bool no_last_bounce_cut = false, no_primary_cull = false, no_primary_reuse = false; // per frame (render_enqueue)
+        bool no_any_hit = false;       // last-bounce queries that hold an emitter stop at the first certain occluder unless set
+        int reuse_quorum = 1;
+        int queue_chunk = 0, queue_counters = 0; // 0: the library's choice
+        bool no_wall_table = false, no_wall_pairs = false, no_stack_spill = false, no_scan_planes = false; // layout (finalize_layout / scene compile)
+        bool lds_fill = false;         // FF_DEBUG_LDS_FILL=words,pattern
+        unsigned long lds_fill_words = 0, lds_fill_pattern = 0;
+        int pool = -1;                 // FF_POOL: -1 the library's choice, 0 the lane-owned traversal kernel, 1 the job-pool kernel
+        int pool_quorum = 0;           // FF_POOL_QUORUM: ready lanes a wave waits for before a setup pass (0: the library's choice)
+        int pool_batch_min = 0;        // FF_POOL_BATCH_MIN: a traversal batch is handed back when fewer lanes are still busy (0: the library's choice)
+    } sw;
     int block_threads = ff::kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
     bool setup_threshold_forced = false;
     int setup_threshold = 14, leaf_threshold = 20; // BVH kernel scheduling knobs: traversal time slice in inner rounds (0 = none) and

@@ -21,9 +21,9 @@ EXPORTS = [
     "ff_scene_info", "ff_debug_wall_table", "ff_debug_wall_entries", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
-    "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_timeline", "ff_debug_check_ieee", "ff_load_obj", "ff_free_triangles",
+    "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_timeline", "ff_debug_check_ieee", "ff_debug_reload_switches", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
-    "ff_dist_unique_id", "ff_dist_init", "ff_dist_available", "ff_dist_shutdown", "ff_dist_strip_rows", "ff_dist_part_bytes", "ff_render_distributed",
+    "ff_dist_unique_id", "ff_dist_init", "ff_dist_available", "ff_dist_shutdown", "ff_dist_strip_rows", "ff_dist_part_bytes", "ff_render_distributed", "ff_debug_dist_fail_rank",
     "ff_multi_create", "ff_multi_destroy", "ff_multi_count", "ff_multi_state", "ff_multi_uses_rccl", "ff_multi_upload_scene",
     "ff_multi_render", "ff_multi_render_to_pbo", "ff_multi_stats",
 ]
@@ -113,6 +113,7 @@ def load():
     lib.ff_debug_kernel_name.argtypes = [vp]
     lib.ff_debug_kernel_name.restype = C.c_char_p
     lib.ff_debug_check_ieee.argtypes = [vp, P(C.c_ulonglong)]
+    lib.ff_debug_reload_switches.argtypes = [vp]
     lib.ff_load_obj.argtypes = [C.c_char_p, P(P(T.FfTriangle)), P(i32)]
     lib.ff_free_triangles.argtypes = [P(T.FfTriangle)]
     lib.ff_free_triangles.restype = None
@@ -125,6 +126,7 @@ def load():
     lib.ff_dist_unique_id.argtypes = [vp, i32]
     lib.ff_dist_init.argtypes = [vp, i32, i32, vp, i32]
     lib.ff_dist_shutdown.argtypes = [vp]
+    lib.ff_debug_dist_fail_rank.argtypes = [vp, C.c_int]
     lib.ff_dist_available.argtypes = []
     lib.ff_dist_strip_rows.argtypes = [i32]
     lib.ff_dist_part_bytes.argtypes = [i32, i32, i32, i32, i32, P(C.c_longlong)]
@@ -309,6 +311,10 @@ class Tracer:
         check(self._lib.ff_debug_check_ieee(self._state, buf))
         return int(buf[0]), int(buf[1])
 
+    def reload_switches(self):
+        """Re-read the FF_* experiment switches from the environment (they are read once, at ff_create)."""
+        check(self._lib.ff_debug_reload_switches(self._state))
+
     def debug_counters(self):
         buf = (C.c_ulonglong * 32)()
         check(self._lib.ff_debug_counters(self._state, buf))
@@ -400,6 +406,10 @@ class Tracer:
 
     def dist_shutdown(self):
         check(self._lib.ff_dist_shutdown(self._state))
+
+    def debug_dist_fail_rank(self, rank):
+        """Tests: rank `rank` reports an injected local failure from the next distributed frame on (-1: off)."""
+        check(self._lib.ff_debug_dist_fail_rank(self._state, rank))
 
     def render_distributed(self, camera, params, strip_rows=0, rank=0, want_rgb8=True, want_radiance=True):
         """One frame over all ranks; returns (rgb8, radiance) host arrays on rank 0, (None, None) elsewhere."""

@@ -213,6 +213,9 @@ FF_API long long ff_dist_part_bytes(int width, int height, int strip_rows, int p
  * made a new one.  After such an error the process should exit; a fresh process is the retry. */
 FF_API int ff_render_distributed(FfState* state, const FfCamera* camera, const FfRenderParams* params, int strip_rows,
                                  void* rgb8, int rgb8_on_device, float* radiance, int radiance_on_device);
+/* Tests: from the next frame on, rank `rank` of the job reports an injected local failure (FF_ERR_OOM) before its strips are
+ * enqueued; -1 switches it off.  FF_DEBUG_DIST_FAIL_RANK in the environment at ff_dist_init sets the initial value. */
+FF_API int ff_debug_dist_fail_rank(FfState* state, int rank);
 
 /* Shape 2 — one process, several GPUs: what a single-process viewer (the reference's main(), kernel.cu:223-368) calls.
  * ff_multi_create makes one state per entry of device_ids, each with its own stream; device_ids[0] is the gathering device
@@ -291,6 +294,10 @@ FF_API int ff_debug_timeline(FfState* state, unsigned* out1024, int* bucket_us);
 /* Self-check of the kernels' arithmetic: their correctly rounded 1/x and sqrt(x) against the compiler's IEEE expansions on
  * every one of the 2^32 float bit patterns; out_mismatches2[0] / [1] must come back 0 (a few milliseconds). */
 FF_API int ff_debug_check_ieee(FfState* state, unsigned long long* out_mismatches2);
+/* The experiment switches (FF_NO_PRIMARY_REUSE, FF_NO_LAST_BOUNCE_CUT, FF_NO_WALL_TABLE, FF_POOL, ...) are read from the
+ * environment once, at ff_create; this re-reads them for `state` (A/B tests that flip a switch between two frames of one state).
+ * Layout switches take effect at the next upload or transform update. */
+FF_API int ff_debug_reload_switches(FfState* state);
 
 /* ---- mesh loading (next-row scope: LoadMesh, utilities.h:781-840) ------------------------------- */
 

@@ -46,9 +46,18 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
-def tracer():
+def _session_tracer():
     """One Tracer for the whole GPU session (a single process owns the card)."""
     from gpupathtracer_amd import lib
     t = lib.Tracer(0)
     yield t
     t.close()
+
+
+@pytest.fixture
+def tracer(_session_tracer):
+    """The session's Tracer.  The library reads its FF_* experiment switches once, at ff_create: a test that flips one calls
+    tracer.reload_switches(); whatever it left behind is re-read here from the restored environment (this fixture is set up
+    before `monkeypatch` where a test lists it first, so it is torn down after the environment is back)."""
+    yield _session_tracer
+    _session_tracer.reload_switches()

@@ -98,11 +98,11 @@ def test_rccl_transport_on_a_one_rank_communicator(monkeypatch):
         assert t.stats().rays_traced > 0
         # A rank that fails before the gather (here: injected) is an error of the frame, not a stuck receive: the ranks agree on a
         # status first (a 4-byte all-reduce behind the strips), nobody posts the gather, and the communicator stays usable.
-        monkeypatch.setenv("FF_DEBUG_DIST_FAIL_RANK", "0")
+        t.debug_dist_fail_rank(0)
         with pytest.raises(lib.FireflyError) as e:
             t.render_distributed(cam, params)
         assert e.value.status == T.FF_ERR_OOM and "injected" in str(e.value)
-        monkeypatch.delenv("FF_DEBUG_DIST_FAIL_RANK")
+        t.debug_dist_fail_rank(-1)
         assert _same(t.render_distributed(cam, params, 8), ref)
         # invalid arguments on a joined rank go through the same agreement
         bad = lib.render_params(w, h, 0, 3)

@@ -122,10 +122,12 @@ def test_big_scenes_with_walls_screened_first(tracer, walls, crowd):
     assert np.array_equal(got["tri"][hit], exp["tri"][hit]) and np.array_equal(got["point"][hit].view(np.uint32), exp["point"][hit].view(np.uint32))
     os.environ["FF_NO_SCAN_PLANES"] = "1"
     try:
+        tracer.reload_switches()  # (the switches are read at ff_create)
         tracer.upload_scene(scene)
         same = tracer.render(cam, lib.render_params(w, h, 6, 3, 5))
     finally:
         del os.environ["FF_NO_SCAN_PLANES"]
+        tracer.reload_switches()
     assert np.array_equal(same[1].view(np.uint32), bvh[1].view(np.uint32))
 
 

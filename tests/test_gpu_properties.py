@@ -332,6 +332,7 @@ def test_work_queue_knobs_do_not_change_a_bit(tracer, monkeypatch):
     for counters, chunk in (("1", "1"), ("3", "7"), ("16", "64"), ("64", "4096"), ("5", "100")):
         monkeypatch.setenv("FF_QUEUE_COUNTERS", counters)
         monkeypatch.setenv("FF_QUEUE_CHUNK", chunk)
+        tracer.reload_switches()
         got = frames()
         for name in cases:
             assert got[name][2] == ref[name][2], (counters, chunk, name)
@@ -342,9 +343,11 @@ def test_work_queue_knobs_do_not_change_a_bit(tracer, monkeypatch):
         p = lib.render_params(w, h, 3, 300, 9)
         monkeypatch.delenv("FF_QUEUE_COUNTERS")
         monkeypatch.delenv("FF_QUEUE_CHUNK")
+        t.reload_switches()
         a = t.render(cam, p)[1].view(np.uint32).copy()
         monkeypatch.setenv("FF_QUEUE_COUNTERS", "7")
         monkeypatch.setenv("FF_QUEUE_CHUNK", "33")
+        t.reload_switches()
         b = t.render(cam, p)[1].view(np.uint32).copy()
         assert t.stats().flags & T.FF_STATS_TAIL_ITEMS
     assert np.array_equal(a, b)
@@ -466,8 +469,10 @@ def test_primary_rays_that_miss_the_scene_box_are_dropped_at_the_queue(tracer, m
             assert np.array_equal(bvh[0], brute[0]) and np.array_equal(bvh[1].view(np.uint32), brute[1].view(np.uint32))
             params.trace_mode = T.TRACE_BVH
             monkeypatch.setenv("FF_NO_PRIMARY_CULL", "1")
+            tracer.reload_switches()
             off = tracer.render(cam, params)
             monkeypatch.delenv("FF_NO_PRIMARY_CULL")
+            tracer.reload_switches()
             assert rays == tracer.stats().rays_traced and np.array_equal(bvh[1].view(np.uint32), off[1].view(np.uint32))
         # a tile across the silhouette of the box and the strips of a three-part frame carry the full frame's pixels
         params = lib.render_params(w, h, 4, 3, 8)
@@ -484,6 +489,7 @@ def test_repeated_primary_rays_are_answered_from_the_block_cache(tracer, monkeyp
     blocks per pixel (camera inside the box: no pixel is culled); with diffuse, mirror and glass surfaces, one bounce (every
     path is its primary segment), partial last blocks, several launches per frame and interpolated normals."""
     monkeypatch.setenv("FF_NO_PRIMARY_CULL", "1")  # (its pixels would count as answered as well)
+    tracer.reload_switches()
     inside = scenes.posed_camera(96, 64, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     # the open scene from outside: most primary rays hit nothing - the first sample of a block finds that out and is the block's
     # last (a block of zeros adds up to zero); the others count as answered all the same
@@ -502,18 +508,22 @@ def test_repeated_primary_rays_are_answered_from_the_block_cache(tracer, monkeyp
             else:
                 assert 0 < st.rays_answered <= 96 * 64 * (spp - blocks)
             monkeypatch.setenv("FF_NO_PRIMARY_REUSE", "1")
+            tracer.reload_switches()
             off = tracer.render(cam, params)
             st_off = tracer.stats()
             monkeypatch.delenv("FF_NO_PRIMARY_REUSE")
+            tracer.reload_switches()
             assert st_off.rays_answered == 0 and st_off.rays_traced == st.rays_traced
             assert np.array_equal(on[0], off[0]) and np.array_equal(on[1].view(np.uint32), off[1].view(np.uint32))
             # FF_REUSE_QUORUM: lanes with a parked hit wait for the next iteration's shading unless that many of them are ready
             # (65: they always wait, also when no other lane of the wave has a query left)
             for quorum in ("5", "65"):
                 monkeypatch.setenv("FF_REUSE_QUORUM", quorum)
+                tracer.reload_switches()
                 held = tracer.render(cam, params)
                 st_q = tracer.stats()
                 monkeypatch.delenv("FF_REUSE_QUORUM")
+                tracer.reload_switches()
                 assert st_q.rays_answered == st.rays_answered and st_q.rays_traced == st.rays_traced
                 assert np.array_equal(on[1].view(np.uint32), held[1].view(np.uint32))
             if spp <= 200:
@@ -544,9 +554,11 @@ def test_last_bounce_queries_end_after_the_planes_when_no_emitter_is_held(tracer
             assert (st.rays_cut_short > 0) == cuts, (bounces, spp, st.rays_cut_short)
             assert st.rays_cut_short <= 96 * 64 * spp  # at most one last segment per path
             monkeypatch.setenv("FF_NO_LAST_BOUNCE_CUT", "1")
+            tracer.reload_switches()
             off = tracer.render(cam, params)
             st_off = tracer.stats()
             monkeypatch.delenv("FF_NO_LAST_BOUNCE_CUT")
+            tracer.reload_switches()
             assert st_off.rays_cut_short == 0 and st_off.rays_traced == st.rays_traced
             assert np.array_equal(on[0], off[0]) and np.array_equal(on[1].view(np.uint32), off[1].view(np.uint32))
             params.trace_mode = T.TRACE_BRUTE_FORCE

@@ -233,3 +233,19 @@ def test_wall_table_takes_axis_aligned_planes_only(ff):
         assert np.array_equal(table(box), w_box)
     finally:
         del os.environ["FF_NO_WALL_PAIRS"]
+
+
+def test_builder_arrivals_wait_for_their_stores():
+    """the bottom-up builders of csrc/ff_build.hip hand boxes from thread to thread through agent-scope (sc1)
+    stores and an arrival counter; the release is `s_waitcnt vmcnt(0)` in front of the arrival atomic (release_arrival).  The
+    check compiles the file for gfx950 (no GPU needed) and scans the ISA: no sc1 store may reach a global_atomic_add without that
+    wait in between."""
+    import shutil
+    import subprocess
+    import sys as _sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_arrivals.py")
+    out = subprocess.run([_sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 violations" in out.stdout and " 0 arrival atomics" not in out.stdout
