@@ -64,6 +64,17 @@ def algorithmic_bytes(st, width, rows, spp):
 
 
 def measured_pmc(args, world, kernel):
+    """(measurement or None, why not, scope): with N > 1 ranks there is no N-GPU counter file (the pool's boxes have one GPU); a rank
+    runs the same kernel instantiation on a strip subset of the same frame, so the N = 1 file's PER-RAY figures apply when kernel
+    name and source hash match: scope "n1" (the live rays and launch duration are this run's own)."""
+    found, why = _measured_pmc(args, world, kernel)
+    if found is not None or world == 1:
+        return found, why, "exact"
+    found, why1 = _measured_pmc(args, 1, kernel)
+    return (found, None, "n1") if found is not None else (None, why, None)
+
+
+def _measured_pmc(args, world, kernel):
     """The committed PMC measurement of the dominant kernel (profiles/*_pmc.json: rocprofv3 --pmc, separate passes,
     tools/pmc_passes.sh + tools/pmc_to_json.py) taken on exactly this workload and kernel instantiation AND on the kernel
     sources of this tree (kernel_source_hash: a counter file from other sources says nothing about this kernel).  Returns
@@ -202,63 +213,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return int(t.item()) == 1
 
-    if world > 1 and backend == "nccl":
-        os.environ.setdefault("FF_DIST_TIMEOUT_S", "120")  # a stuck native gather becomes an error after two minutes, not a hang
-        # Every rank runs every collective below whatever failed locally: a rank that skipped one would leave the others inside it.
-        able = lib.dist_available()
-        uid = None
-        if rank == 0 and able:
-            try:
-                uid = lib.dist_unique_id()
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank 0: ff_dist_unique_id failed ({e})", file=sys.stderr, flush=True)
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)  # (None when rank 0 has no id to give)
-        if all_agree(able and box[0] is not None):  # only if ALL ranks can join do any of them enter ff_dist_init, which blocks until all have
-            joined = False
-            try:
-                tracer.dist_init(rank, world, box[0])
-                joined = True
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: ff_dist_init failed ({e})", file=sys.stderr, flush=True)
-            if all_agree(joined):
-                gather = "native-rccl"
-            else:
-                gather, gather_note = "torch-rccl", "ff_dist_init failed on some rank"
-                if joined:
-                    tracer.dist_shutdown()
-        else:
-            gather, gather_note = "torch-rccl", "RCCL could not be loaded by the library on some rank"
-    elif world > 1:
-        gather = "torch-" + backend
     full_rgb8 = torch.empty((args.height, args.width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
     full_rad = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
-    if gather == "native-rccl":
-        # Self-check before anything is timed: one short frame through the native gather against the same frame rendered by rank 0
-        # alone, bit for bit (rows in the wrong place, a wrong part offset or a lost message cannot hide in a rate).  Any error
-        # or difference on any rank sends ALL ranks to torch.distributed's gather, and the JSON line says so.
+
+    def native_self_check():
+        """One short frame through the native gather against the same frame rendered by rank 0 alone, bit for bit (rows in the
+        wrong place, a wrong part offset or a lost message cannot hide in a rate)."""
         vparams = lib.render_params(args.width, args.height, args.bounces, min(args.spp, 8), args.seed, mode, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
-        good = True
-        try:
-            tracer.render_distributed_device(camera, vparams, strip_rows, full_rgb8.data_ptr() if rank == 0 else None,
-                                             full_rad.data_ptr() if rank == 0 else None)
-            if rank == 0:
-                torch.cuda.synchronize()
-                got8, gotr = full_rgb8.clone(), full_rad.clone()
-                tracer.render_device(camera, vparams, full_rgb8.data_ptr(), full_rad.data_ptr())
-                torch.cuda.synchronize()
-                good = bool(torch.equal(got8, full_rgb8)) and bool(torch.equal(gotr.view(torch.int32), full_rad.view(torch.int32)))
-                if not good:
-                    print("[bench] rank 0: the natively gathered frame differs from the frame rendered alone", file=sys.stderr, flush=True)
-        except Exception as e:  # noqa: BLE001
-            good = False
-            print(f"[bench] rank {rank}: native gather failed its self-check ({e})", file=sys.stderr, flush=True)
-        if not all_agree(good):
-            gather, gather_note = "torch-rccl", "the native RCCL gather failed its bitwise self-check against a frame rendered by rank 0 alone"
-            try:
-                tracer.dist_shutdown()
-            except Exception:  # noqa: BLE001
-                pass
+        tracer.render_distributed_device(camera, vparams, strip_rows, full_rgb8.data_ptr() if rank == 0 else None,
+                                         full_rad.data_ptr() if rank == 0 else None)
+        if rank != 0:
+            return True
+        torch.cuda.synchronize()
+        got8, gotr = full_rgb8.clone(), full_rad.clone()
+        tracer.render_device(camera, vparams, full_rgb8.data_ptr(), full_rad.data_ptr())
+        torch.cuda.synchronize()
+        same = bool(torch.equal(got8, full_rgb8)) and bool(torch.equal(gotr.view(torch.int32), full_rad.view(torch.int32)))
+        if not same:
+            print("[bench] rank 0: the natively gathered frame differs from the frame rendered alone", file=sys.stderr, flush=True)
+        return same
+
+    if world > 1 and backend == "nccl":
+        os.environ.setdefault("FF_DIST_TIMEOUT_S", "120")  # a stuck native gather becomes an error after two minutes, not a hang
+
+        def broadcast(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        # (the decision tree - every rank runs every collective whatever failed locally - lives in gpupathtracer_amd/dist.py, where
+        # tests/test_dist_gloo.py drives it over gloo with a stubbed library for each failure shape)
+        gather, gather_note = ffdist.negotiate_native_gather(
+            rank, world, able=lib.dist_available(), make_id=lib.dist_unique_id, join=lambda uid: tracer.dist_init(rank, world, uid),
+            leave=tracer.dist_shutdown, self_check=native_self_check, broadcast=broadcast, all_agree=all_agree,
+            log=lambda text: print("[bench] " + text, file=sys.stderr, flush=True))
+    elif world > 1:
+        gather = "torch-" + backend
     rgb8 = rad = None
     if gather != "native-rccl":
         rgb8 = torch.empty((max(local_rows, 1), args.width, 3), dtype=torch.uint8, device=device)
@@ -348,7 +338,7 @@ def main():
         mean_launch_s = kernel_ms / max(1, launches) / 1e3
         rays_per_launch = rays / max(1, launches)
         algo_bytes_launch = algorithmic_bytes(counted, args.width, local_rows, args.spp) / max(1, counted.kernel_launches)
-        pmc, pmc_why_not = measured_pmc(args, world, kernel)
+        pmc, pmc_why_not, pmc_scope = measured_pmc(args, world, kernel)
         roof = {
             # What binds this kernel is VALU issue at partial lane occupancy, not HBM: the scene is
             # LDS/L2 resident.  achieved = wave-level VALU instructions per second, from the committed PMC count per ray of
@@ -359,6 +349,10 @@ def main():
             "algorithmic_GBps": round(algo_bytes_launch / mean_launch_s / 1e9, 1),
             "per_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced), 3),
                         "tris": round(counted.tris_tested / max(1, counted.rays_traced), 3)},
+            # the same per path segment that went through the closest-hit machinery (all segments minus those answered from a
+            # block's parked primary hit or dropped with a culled pixel); `valu` joins it below when a PMC file matches
+            "per_traversed_ray": {"nodes": round(counted.nodes_visited / max(1, counted.rays_traced - counted.rays_answered), 3),
+                                  "tris": round(counted.tris_tested / max(1, counted.rays_traced - counted.rays_answered), 3)},
         }
         if pmc is not None:
             achieved = pmc["valu_insts_per_ray"] * rays_per_launch / mean_launch_s / 1e9
@@ -369,10 +363,12 @@ def main():
                 "traffic": int(traffic), "hbm_GBps": round(traffic / mean_launch_s / 1e9, 2),
                 "hbm_frac": round(traffic / mean_launch_s / 1e9 / HBM_PEAK_GBS, 5),
                 "algorithmic_vs_hbm": round(algo_bytes_launch / max(traffic, 1.0), 1),
-                "pmc_source": pmc["file"], "pmc_kernel_source_hash": pmc["kernel_source_hash"],
+                "pmc_source": pmc["file"], "pmc_kernel_source_hash": pmc["kernel_source_hash"], "pmc_scope": pmc_scope,
                 "note": "algorithmic bytes (SURVEY.md section 8d: 24/ray + 112/node visit + 48/triangle test + framebuffer) are served by LDS and L2; "
                         "`traffic` is what reaches HBM (FETCH_SIZE x2 + WRITE_SIZE from the PMC passes, scaled by rays)",
             })
+            roof["per_ray"]["valu"] = round(pmc["valu_insts_per_ray"], 2)
+            roof["per_traversed_ray"]["valu"] = round(pmc["valu_insts_per_ray"] * total_rays / max(1.0, total_rays - total_answered), 2)
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None, "note": "PMC-derived fields withheld: " + pmc_why_not})
         frame_ms.sort()
@@ -383,20 +379,22 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "frames_per_s": round(1e3 / ms_per_step, 4),
             "ms_per_frame_min": round(frame_ms[0], 3), "ms_per_frame_median": round(frame_ms[len(frame_ms) // 2], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # `value` counts ALL path segments, as in every round.  Of those, `untraversed_frac` never reached the closest-hit machinery
+            # (repeated primary rays of a sample block answered from its parked hit - kernel.cu:200-205 has no jitter - and the rays of
+            # culled pixels); `traversed_Mrays_per_s` is the rate of the rest.  ms/frame is the number to compare across rounds.
+            "traversed_Mrays_per_s": round((total_rays - total_answered) / elapsed / 1e6, 2),
+            "untraversed_frac": round(total_answered / max(1.0, total_rays), 4),
             "config": {
                 "workload": f"{scene_name}, {args.width}x{args.height}, "
                             f"{args.bounces} bounces, {args.spp} spp, camera={args.camera}, trace={args.trace_mode}, seed {args.seed}",
                 "scene": args.scene,
                 "rays_per_frame": int(total_rays / args.steps),
-                # of those path segments, the ones answered without a traversal: the repeated primary rays of a sample block (every
-                # sample of a pixel starts with the same ray, kernel.cu:200-205: traced once per block) and the
-                # primary rays of pixels whose view of the scene box is empty (camera outside the scene).  `value` counts all path
-                # segments, as in every round; `traversed_Mrays_per_s` only those that went through the closest-hit machinery
-                "rays_answered_without_traversal_per_frame": int(total_answered / args.steps),
-                "traversed_Mrays_per_s": round((total_rays - total_answered) / elapsed / 1e6, 2),
-                # ... and the last segments of paths that ended after the planes were screened: only an emitter can still add radiance
-                # there, the scene's emitters are planes, and none was among the query's candidates (the meshes were not walked)
-                "rays_cut_short_after_the_planes_per_frame": int(total_cut / args.steps),
+                # rays_untraversed: path segments per frame answered without a traversal (top level: untraversed_frac);
+                # rays_cut_last: last segments of paths that ended after the analytic records were screened (only an emitter can still
+                # add radiance there and the query held none: the meshes were not walked); rays_any_hit: last segments that held an
+                # emitter and stopped at the first certain occluder in front of it
+                "rays_untraversed": int(total_answered / args.steps),
+                "rays_cut_last": int(total_cut / args.steps),
                 "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
                 "gather": gather if gather_note is None else f"{gather} ({gather_note})",
             },

@@ -74,3 +74,54 @@ def deinterleave_host(blocks, height, strip_rows, num_parts):
         out[idx] = blocks[off: off + len(idx)]
         off += len(idx)
     return out
+
+
+def negotiate_native_gather(rank, world_size, *, able, make_id, join, leave, self_check, broadcast, all_agree, log=None):
+    """Which gather does a multi-rank job use: the library's own RCCL transport (ff_render_distributed) or torch.distributed's?
+
+    Every rank calls this with the same `world_size` and runs EVERY collective below whatever failed locally - a rank that skipped
+    one would leave the others inside it.  Order: (1) all ranks agree that RCCL can be loaded by the library (`able`) and that rank
+    0 produced a communicator id (`make_id()`, broadcast to all; None when it could not); (2) only then does any rank enter
+    `join(id)` (ff_dist_init blocks until every rank has), and all agree that it worked; (3) `self_check()` - one short frame
+    through the native gather compared bitwise, on rank 0, with the same frame rendered by rank 0 alone - and all agree on its
+    result.  Any failure on any rank sends ALL ranks to torch's gather; a rank that had joined leaves (`leave()`).
+
+    Callables: make_id() -> bytes (rank 0 only; may raise), join(id) (may raise), leave() (errors ignored), self_check() -> bool
+    (may raise), broadcast(obj) -> obj of rank 0, all_agree(flag) -> True iff flag holds on every rank, log(str).
+    Returns (gather, note): ("native-rccl", None) or ("torch-rccl", why).
+    """
+    say = log if log is not None else (lambda text: None)
+    uid = None
+    if rank == 0 and able:
+        try:
+            uid = make_id()
+        except Exception as e:  # noqa: BLE001
+            say(f"rank 0: ff_dist_unique_id failed ({e})")
+    uid = broadcast(uid)  # (None when rank 0 has no id to give)
+    if not all_agree(bool(able) and uid is not None):
+        return "torch-rccl", "RCCL could not be loaded by the library on some rank, or rank 0 could not make a communicator id"
+    joined = False
+    try:
+        join(uid)
+        joined = True
+    except Exception as e:  # noqa: BLE001
+        say(f"rank {rank}: ff_dist_init failed ({e})")
+    if not all_agree(joined):
+        if joined:
+            try:
+                leave()
+            except Exception:  # noqa: BLE001
+                pass
+        return "torch-rccl", "ff_dist_init failed on some rank"
+    good = False
+    try:
+        good = bool(self_check())
+    except Exception as e:  # noqa: BLE001
+        say(f"rank {rank}: native gather failed its self-check ({e})")
+    if not all_agree(good):
+        try:
+            leave()
+        except Exception:  # noqa: BLE001
+            pass
+        return "torch-rccl", "the native RCCL gather failed its bitwise self-check against a frame rendered by rank 0 alone"
+    return "native-rccl", None

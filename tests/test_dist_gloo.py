@@ -85,3 +85,83 @@ def test_gather_wire_layout_and_parts_without_rows(ff):
         if (w, h, sr, n) == (96, 20, 4, 8):
             assert senders == [0, 1, 2, 3, 4]
     assert lib.ff_dist_part_bytes(8, 8, 0, 0, 1, None) == -1 and lib.ff_dist_part_bytes(8, 8, 4, 2, 2, None) == -1
+
+
+# ---- bench.py's native / torch gather decision (gpupathtracer_amd.dist.negotiate_native_gather) with a stubbed library ----
+
+def _negotiate_worker(rank, world, port, shape, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    try:
+        def broadcast(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        def all_agree(flag):
+            t = torch.tensor([1 if flag else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        def make_id():
+            calls.append("make_id")
+            if shape == "no_id":
+                raise RuntimeError("rccl: no id for you")
+            return b"\x07" * 128
+
+        def join(uid):
+            calls.append("join")
+            assert uid == b"\x07" * 128
+            if shape == "init_fails_on_1" and rank == 1:
+                raise RuntimeError("ncclCommInitRank failed")
+
+        def leave():
+            calls.append("leave")
+
+        def self_check():
+            calls.append("self_check")
+            if shape == "self_check_differs":
+                return rank != 0  # rank 0 sees a frame that differs from its own
+            if shape == "self_check_raises_on_1" and rank == 1:
+                raise RuntimeError("FF_ERR_COMM")
+            return True
+
+        able = not (shape == "cannot_load_on_1" and rank == 1)
+        gather, note = ffdist.negotiate_native_gather(rank, world, able=able, make_id=make_id, join=join, leave=leave, self_check=self_check,
+                                                      broadcast=broadcast, all_agree=all_agree)
+        # every rank must still be able to run a collective afterwards: nobody is stuck inside one
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        with open(os.path.join(out_dir, f"r{rank}"), "w") as f:
+            f.write(f"{gather}|{note}|{','.join(calls)}|{int(t.item())}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", ["all_well", "no_id", "cannot_load_on_1", "init_fails_on_1", "self_check_differs", "self_check_raises_on_1"])
+def test_native_gather_negotiation_leaves_no_rank_behind(tmp_path, shape):
+    """the decision tree bench.py runs before anything is timed, over gloo with a stubbed library, for the
+    failure shapes a first multi-GPU run can meet: rank 0 has no communicator id; one rank cannot load RCCL; one rank fails
+    ff_dist_init; the self-check frame differs (or raises) on one rank.  In every shape all ranks take the SAME decision, a rank
+    that had joined leaves, nobody enters ff_dist_init unless all can, and every rank reaches the collective that follows."""
+    world = 3
+    port = _free_port()
+    mp.spawn(_negotiate_worker, args=(world, port, shape, str(tmp_path)), nprocs=world, join=True)
+    got = [(tmp_path / f"r{r}").read_text().split("|") for r in range(world)]
+    decisions = {g[0] for g in got}
+    assert len(decisions) == 1 and all(g[3] == str(sum(range(1, world + 1))) for g in got)
+    decision = decisions.pop()
+    calls = [g[2].split(",") if g[2] else [] for g in got]
+    if shape == "all_well":
+        assert decision == "native-rccl" and all(g[1] == "None" for g in got)
+        assert all(c[-2:] == ["join", "self_check"] and "leave" not in c for c in calls)
+    else:
+        assert decision == "torch-rccl" and all(g[1] != "None" for g in got)
+    if shape in ("no_id", "cannot_load_on_1"):
+        assert all("join" not in c for c in calls)  # nobody entered ff_dist_init
+    if shape == "init_fails_on_1":
+        assert "leave" in calls[0] and "leave" in calls[2] and "leave" not in calls[1] and all("self_check" not in c for c in calls)
+    if shape in ("self_check_differs", "self_check_raises_on_1"):
+        assert all("leave" in c for c in calls)
