@@ -116,12 +116,12 @@ int lds_records(const FfState* s) { return s->num_geoms > kMaxLdsRecords ? 0 : s
 // Workgroup size of the BVH kernel for the uploaded scene: the preferred size if the lane-strided traversal stacks
 // (4 bytes x workgroup size per tree level) and the geometry records fit the 160 KiB of LDS, else the largest smaller
 // instantiation that does; 0 if even 512 threads do not fit (a degenerate, chain-like device-built tree).
-int bvh_block_threads(const FfState* s, int preferred)
+int bvh_block_threads(const FfState* s, int preferred, int stack_levels)
 {
     const int sizes[3] = { 1024, 768, 512 };
     for (int b : sizes) {
         if (b > preferred) continue;
-        if (bvh_lds_bytes(0, s->stack_entries, b, lds_records(s)) <= (size_t)kLdsBudgetBytes) return b;
+        if (bvh_lds_bytes(0, stack_levels, b, lds_records(s)) + (s->use_pool ? pool_lds_bytes(b) : 0) <= (size_t)kLdsBudgetBytes) return b;
     }
     return 0;
 }
@@ -169,7 +169,18 @@ int finalize_layout(FfState* s)
         s->setup_threshold = std::max(4, std::min(24, (int)std::lround(1.5 * std::log((double)biggest) / std::log(4.0) - 0.7)));
         s->setup_threshold = std::min(32, s->setup_threshold + 2 * s->top_depth); // big scenes: plus the walk through the geometry tree
     }
-    s->scene_block_threads = bvh_block_threads(s, s->block_threads);
+    // The job-pool kernel (trace_pool_kernel; scenes of up to kChunkGeometries geometries) parks its traversal jobs in LDS: 48 bytes
+    // per thread + the queue, taken off the node cache.  Its stacks keep a fixed few levels in LDS whether or not the trees fit
+    // (kPoolStackLevels; the deeper entries go to the global spill area): with the jobs in LDS a tree of more than a few hundred
+    // nodes does not fit anyway, and a level costs 36 nodes.
+    s->use_pool = s->sw.pool != 0 && s->num_geoms <= kChunkGeometries && nodes4 > 0;
+    constexpr int kPoolStackLevels = 5;
+    const int pool_levels = std::min(s->stack_entries, s->sw.pool_stack_levels > 0 ? s->sw.pool_stack_levels : kPoolStackLevels);
+    s->scene_block_threads = bvh_block_threads(s, s->block_threads, s->use_pool ? pool_levels : s->stack_entries);
+    if (s->use_pool && s->scene_block_threads == 0) {
+        s->use_pool = false;
+        s->scene_block_threads = bvh_block_threads(s, s->block_threads, s->stack_entries);
+    }
     // (a tree too deep even for 512 threads still uploads: brute-force rendering works, BVH rendering reports it)
     const int block = s->scene_block_threads > 0 ? s->scene_block_threads : kBlockThreads;
     // LDS holds tree nodes and the lanes' traversal stacks.  A stack level costs 4 bytes x workgroup size = 36 nodes at 1 024
@@ -179,8 +190,13 @@ int finalize_layout(FfState* s)
     // global memory costs a query hundreds of cycles, a spilled stack entry is rare.  Trees that do not fit anyway keep the
     // whole stack in LDS.
     constexpr int kMinLdsStack = 4;
+    const size_t reserve = s->use_pool ? pool_lds_bytes(block) : 0;
     s->stack_lds_levels = s->stack_entries;
-    if (s->scene_block_threads > 0 && !s->sw.no_stack_spill) {
+    if (s->use_pool) {
+        s->stack_lds_levels = pool_levels;
+        // (where everything fits with more levels, take them)
+        while (s->stack_lds_levels < s->stack_entries && max_lds_nodes(s->stack_lds_levels + 1, block, lds_records(s), reserve) >= nodes4) ++s->stack_lds_levels;
+    } else if (s->scene_block_threads > 0 && !s->sw.no_stack_spill) {
         const int want = nodes4 + s->top_count;
         if (want > max_lds_nodes(s->stack_entries, block, lds_records(s))) {
             int levels = s->stack_entries;
@@ -188,7 +204,7 @@ int finalize_layout(FfState* s)
             if (max_lds_nodes(levels, block, lds_records(s)) >= want) s->stack_lds_levels = levels;
         }
     }
-    const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_lds_levels, block, lds_records(s))) : 0;
+    const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_lds_levels, block, lds_records(s), reserve)) : 0;
     s->lds_cap = std::min(cap, nodes4 + s->top_count);
     // the geometry tree first (every query of a big scene starts there), the meshes share the rest
     s->top_lds_count = std::min(s->top_count, cap);
@@ -343,7 +359,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if (s->sw.lds_fill) {
         const unsigned long words = s->sw.lds_fill_words, pattern = s->sw.lds_fill_pattern;
         if (prm->trace_mode == FF_TRACE_BVH) {
-            const size_t bytes = bvh_lds_bytes(s->lds_cap, s->stack_lds_levels, block_threads, lds_records(s));
+            const size_t bytes = bvh_lds_bytes(s->lds_cap, s->stack_lds_levels, block_threads, lds_records(s)); // (the pool behind it is initialised by the kernel)
             k.debug_lds_words = (unsigned)std::min<size_t>(words, bytes / 4);
             k.debug_lds_pattern = (unsigned)pattern;
         }
@@ -413,11 +429,26 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     if (grid < 1) grid = 1;
     k.primary_cache = nullptr;
     k.reuse_quorum = s->sw.reuse_quorum;
+    // job-pool kernel: the defaults are where the same-box sweeps put them (profiles/r04_*pool_sweep*)
+    k.pool_quorum = s->sw.pool_quorum > 0 ? s->sw.pool_quorum : 40;
+    k.pool_quorum_min = std::min(k.pool_quorum, s->sw.pool_quorum_min > 0 ? s->sw.pool_quorum_min : 16);
+    k.pool_refill = s->sw.pool_refill > 0 ? s->sw.pool_refill : 16;
+    k.pool_slice = s->sw.pool_slice > 0 ? s->sw.pool_slice : 4;
+    k.pool_leave = s->sw.pool_leave >= 0 ? s->sw.pool_leave : 24;
+    // (instrumented launches with a timeline run the lane-owned kernel, which keeps it; the LDS layout serves both)
+    const bool pool = s->use_pool && prm->trace_mode == FF_TRACE_BVH && !(s->collect_stats && s->timeline_bucket_us > 0);
     if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !s->sw.no_primary_reuse) {
         // one slot per thread of the launch for the closest hit of its sample block's primary ray (trace_bvh_kernel)
         const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)grid * (size_t)block_threads * sizeof(float4));
         if (cst != FF_OK) return cst;
         k.primary_cache = s->d_primary_cache;
+    }
+    k.park = nullptr;
+    if (pool) {
+        // where a lane's own path and query state waits between setup passes (trace_pool_kernel): 7 x 16 bytes per thread of the launch
+        const int pst = ensure_bytes((void**)&s->d_park, &s->park_bytes, (size_t)7 * (size_t)grid * (size_t)block_threads * sizeof(float4));
+        if (pst != FF_OK) return pst;
+        k.park = s->d_park;
     }
     if (prm->trace_mode == FF_TRACE_BVH && s->stack_lds_levels < s->stack_entries) {
         // the stack levels that did not get LDS (finalize_layout): one int per level and thread of the launch
@@ -524,7 +555,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
         if (l > 0) FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
-        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st, &s->last_kernel_name));
+        FF_HIP(launch_trace(k, prm->trace_mode, s->collect_stats, grid, block_threads, st, &s->last_kernel_name, pool));
     }
     FF_HIP(launch_combine(k, st));
     FF_HIP(hipEventRecord(s->ev_end, st));
@@ -606,7 +637,11 @@ void read_switches(FfState* s)
     if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) w.lds_fill = std::sscanf(e, "%lu,%lx", &w.lds_fill_words, &w.lds_fill_pattern) == 2;
     if (const char* e = std::getenv("FF_POOL")) w.pool = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("FF_POOL_QUORUM")) w.pool_quorum = std::max(1, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("FF_POOL_BATCH_MIN")) w.pool_batch_min = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_QUORUM_MIN")) w.pool_quorum_min = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_REFILL")) w.pool_refill = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_SLICE")) w.pool_slice = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_LEAVE")) w.pool_leave = std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_STACK_LEVELS")) w.pool_stack_levels = std::max(1, std::min(64, std::atoi(e)));
     s->sw = w;
 }
 } // namespace
@@ -683,6 +718,7 @@ int ff_destroy(FfState* s)
     if (s->d_stack_spill) (void)hipFree(s->d_stack_spill);
     if (s->d_cull_mask) (void)hipFree(s->d_cull_mask);
     if (s->d_primary_cache) (void)hipFree(s->d_primary_cache);
+    if (s->d_park) (void)hipFree(s->d_park);
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_mean) (void)hipFree(s->d_mean);

@@ -94,6 +94,10 @@ struct KParams {
     int cut_last;
     float scene_min[3], scene_max[3];
     WallTable walls; // axis-aligned planes, screened by a wave-uniform loop (empty for big scenes beyond their first num_scan records)
+    // Job-pool kernel (trace_pool_kernel): a wave runs a setup pass when pool_quorum of its lanes are ready for one (pool_quorum_min
+    // when the job queue is empty), takes new jobs when pool_refill of its lanes are free, traverses in slices of pool_slice inner rounds
+    float4* park; // 7 float4 per thread of the launch, lane-strided: where a lane's own path and query state waits while the lane walks other lanes' jobs
+    int pool_quorum, pool_quorum_min, pool_refill, pool_slice, pool_leave; // pool_leave: a wave that wants to leave the traverse role puts its jobs down once it holds no more than this many
     // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
     // wall clock (100 MHz ticks since the first wave started; counters[27] holds that epoch), kTimelineBuckets buckets
     unsigned* timeline;
@@ -137,12 +141,15 @@ struct RayBatchParams {
 // LDS bytes the BVH kernels need for (lds_nodes, stack_depth).
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms);
 // Largest node count that fits LDS next to a stack of `stack_depth` entries per lane.
-int max_lds_nodes(int stack_depth, int block_threads, int num_geoms);
+int max_lds_nodes(int stack_depth, int block_threads, int num_geoms, size_t reserve = 0);
+// LDS the job-pool kernel needs on top of bvh_lds_bytes: the jobs (48 B per thread), the queue ring and its two counters.
+size_t pool_lds_bytes(int block_threads);
 
 // block_threads: 512 or 1024 for the BVH kernel; the brute-force kernel always runs 512.
 // *kernel_name (optional) receives the name of the instantiation launched, as rocprofv3 prints it.
+// pool: the job-pool kernel (scenes of up to kChunkGeometries geometries; the LDS layout must have left pool_lds_bytes free).
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
-                        const char** kernel_name = nullptr);
+                        const char** kernel_name = nullptr, bool pool = false);
 // Sums every pixel's sample blocks in order, scales by 1/spp and writes radiance / rgb8 (row-major, coalesced).
 hipError_t launch_combine(const KParams& p, hipStream_t stream);
 // Fills mask[pix_items / 64] (see KParams::cull_mask) and zeroes the block sums of the culled pixels.

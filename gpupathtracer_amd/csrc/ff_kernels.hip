@@ -311,6 +311,7 @@ constexpr int kPackedEntry = 0x40000000;                  // stack entry that na
 struct LdsBase {
     int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j
     int stack_base; // uint index of this lane's stack slot 0 (in units of 4 bytes from ff_smem)
+    int stack_slot; // whose stack that is: the thread's own (its index in the workgroup), or, in the job-pool kernel, the job's slot
     int stack_depth; // entries per lane kept in LDS
     int* spill;      // deeper entries: entry e >= stack_depth of thread g of the launch at spill[(e - stack_depth) * threads + g] (null: none).
                      // Wave-uniform (scalar registers); the lane's own address is formed in the rare branch that needs it
@@ -358,6 +359,7 @@ __device__ __forceinline__ LdsT<BIG> make_lds(int node_cap, int stack_depth, int
     L.node_cap = node_cap;
     L.stride = block;
     L.stack_base = node_cap * (kNodeVec4 * 4) + tid;
+    L.stack_slot = tid;
     L.stack_depth = stack_depth;
     L.geom_base = node_cap * kNodeVec4 + (stack_depth * block) / 4;
     return L;
@@ -415,13 +417,13 @@ template <class LDS>
 __device__ __forceinline__ void stack_push(const LDS& L, int sp, int v)
 {
     if (__builtin_expect(sp < L.stack_depth, 1)) reinterpret_cast<int*>(ff_smem)[L.stack_base + sp * L.stride] = v;
-    else L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + threadIdx.x] = v;
+    else L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + (size_t)L.stack_slot] = v;
 }
 template <class LDS>
 __device__ __forceinline__ int stack_pop(const LDS& L, int sp)
 {
     if (__builtin_expect(sp < L.stack_depth, 1)) return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride];
-    return L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + threadIdx.x];
+    return L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + (size_t)L.stack_slot];
 }
 
 // kernel.cu:138 with the geometry record gathered from LDS by a lane-varying index (same arithmetic as object_space_ray).
@@ -1203,8 +1205,9 @@ __device__ __forceinline__ void leaf_step(const LDS& L, const TriRecord* __restr
             An = tp[3 * kn]; E1n = tp[3 * kn + 1]; E2n = tp[3 * kn + 2];
         }
         if (STATS) {
-            // (instrumented launches only: the wait for the three loads is made explicit so that it can be told from the arithmetic)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // (instrumented launches only: the wait for THIS triangle's three loads is made explicit so that it can be told from the
+            // arithmetic; the three youngest loads - the next triangle's, issued just above - stay in flight as in the real kernel)
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
             const unsigned long long tl1 = __builtin_amdgcn_s_memtime();
             if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) tl_wait += tl1 - tl0; // one lane per round keeps the wave's time
             tl0 = tl1;
@@ -2134,6 +2137,603 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     flush_counters(p, lane, cnt, STATS);
 }
 
+// ---- the job-pool mega-kernel ------------------------------------------------------------------------------------------------
+//
+// trace_bvh_kernel keeps a query in the lane that owns its path: when neighbouring rays need very different numbers of node
+// visits, the lanes that are through idle until the wave's next setup pass (inner-node phase: a third of the lanes busy).
+// Here the traversal of one (ray, mesh) pair is a JOB parked in LDS, and ANY wave of the workgroup executes jobs:
+//
+//   * a lane still owns its path (the path state never leaves its registers).  In a SETUP pass the lanes of a wave whose query is
+//     complete (or that have none) resolve, shade, fetch work and screen the planes of their next ray together, exactly as in
+//     trace_bvh_kernel; a lane whose ray can reach a mesh then writes the job - object-space ray, scale, bounds, cursor: 48 bytes
+//     in its own slot of the job array - and puts the slot's number in the workgroup's queue (a ring in LDS);
+//   * in the TRAVERSE role a wave takes jobs from the queue, 64 at a time, and walks them through the 4-wide trees in slices of a
+//     few inner-node rounds; after a slice the lanes whose job is finished hand it back (16 bytes + a flag the owner polls) and,
+//     once enough lanes are free, the wave takes as many new jobs: the inner-node phase runs on nearly full waves whatever the
+//     spread of work between rays.  The traversal stack of a job lives in LDS under the job's slot, so a job can be put down by
+//     one wave (16 bytes written back) and picked up by another;
+//   * a wave runs a setup pass when enough of its own lanes are ready for one (pool_quorum) - or when the queue has nothing
+//     to offer - and traverses otherwise.
+//
+// What crosses the hand-over is only what the walk needs; everything exact stays with the owner: a near tie between a triangle
+// and the candidate the query holds (offer) ends the job with its leaf under the cursor, the owner resolves the held candidate
+// exactly (kernel.cu:110-125) and posts the job again.  Per ray the sequence of box tests, triangle tests, offers and exact
+// evaluations is the one trace_bvh_kernel performs: same bits, same ray counts.
+//
+// Scenes of up to 32 geometries (the reference has five); larger ones run trace_bvh_kernel.
+
+#ifndef FF_POOL_DEBUG
+#define FF_POOL_DEBUG 0
+#endif
+constexpr int kPoolRing = 2048;          // queue entries (16-bit slot numbers): twice the most jobs that can be outstanding, so an
+                                         // entry claimed by a consumer is never the one a producer writes
+constexpr unsigned kRingEmpty = 0xFFFFu;
+constexpr int kPoolSpinLimit = 1 << 20;  // bound on every wait of the pool kernel (a wait that long is a bug: the launch ends with an error instead of hanging)
+constexpr int kPendEmpty = -2;           // job's pending tag: the query holds no pending candidate
+constexpr int kPendOwner = -3;           // ... holds one whose identity stays with the owner (a plane, a triangle of an earlier mesh)
+constexpr unsigned kJobReturned = 0x80000000u; // job word 9 (sp | mesh << 8 | resume << 16): set by the wave that hands the job back
+constexpr unsigned kJobTie = 0x40000000u;      // ... because triangle resume - 1 of the leaf under the cursor met a near tie with the pending candidate
+
+struct PoolRef {
+    int job_base;  // uint4 index: quarter q of job j at job_base + q * BLOCK + j
+    int ring_base; // 16-bit index of ring entry 0
+    int ctrl;      // 32-bit index of [head, tail]
+};
+
+__device__ __forceinline__ unsigned* pool_u32() { return reinterpret_cast<unsigned*>(ff_smem); }
+__device__ __forceinline__ unsigned short* pool_u16() { return reinterpret_cast<unsigned short*>(ff_smem); }
+
+// Put the calling lanes' slots (post) into the queue.  Called by all lanes of the wave.
+__device__ __forceinline__ void pool_push(const PoolRef& Q, int lane, int slot, bool post)
+{
+    const unsigned long long m = __ballot(post);
+    if (m == 0ull) return;
+    // what the job's slot holds was written by this wave before this point: LDS executes a wave's instructions in order, and
+    // the fence keeps the compiler from moving them behind the queue entry
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0u;
+    if (lane == leader) base = __hip_atomic_fetch_add(&pool_u32()[Q.ctrl + 1], (unsigned)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    if (post) {
+        const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        __hip_atomic_store(&pool_u16()[Q.ring_base + (int)((base + rank) & (unsigned)(kPoolRing - 1))], (unsigned short)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// Take up to one job per asking lane (want) from the queue: returns the lane's job slot or -1.  Called by all lanes of the wave
+// in wave-uniform control flow.
+__device__ __forceinline__ int pool_pop(const PoolRef& Q, int lane, bool want, bool& stuck)
+{
+    const unsigned long long m = __ballot(want);
+    const unsigned asked = (unsigned)__popcll(m);
+    unsigned h = 0u, n = 0u;
+    if (lane == 0) {
+        for (int tries = 0; tries < kPoolSpinLimit; ++tries) {
+            h = __hip_atomic_load(&pool_u32()[Q.ctrl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned t = __hip_atomic_load(&pool_u32()[Q.ctrl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            n = min(asked, t - h);
+            if (n == 0u) break;
+            unsigned expect = h;
+            if (__hip_atomic_compare_exchange_strong(&pool_u32()[Q.ctrl], &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            n = 0u; // (if the tries run out: nothing taken)
+        }
+    }
+    h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+    n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+    int slot = -1;
+    const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (want && rank < n) {
+        unsigned short* e = &pool_u16()[Q.ring_base + (int)((h + rank) & (unsigned)(kPoolRing - 1))];
+        unsigned v;
+        // (the producer reserves its entries with one atomic and writes them straight after: a reserved entry that is still
+        // empty is filled within a few instructions of another wave, which nothing here can hold up)
+        int spins = 0;
+        do { v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (v == kRingEmpty && ++spins < kPoolSpinLimit);
+        if (v != kRingEmpty) {
+            __hip_atomic_store(e, (unsigned short)kRingEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            slot = (int)v;
+        } else {
+            stuck = true; // (never in a healthy launch: the caller gives up and the host reports it)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return slot;
+}
+
+// Jobs waiting in the queue (a snapshot).
+__device__ __forceinline__ unsigned pool_waiting(const PoolRef& Q)
+{
+    const unsigned h = __hip_atomic_load(&pool_u32()[Q.ctrl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned t = __hip_atomic_load(&pool_u32()[Q.ctrl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return t - h;
+}
+
+// The third quarter of a job: what a traversal changes.  (cursor, sp | mesh << 8 | resume << 16 [| kJobReturned], pending distance, pending tag)
+__device__ __forceinline__ uint4 job_state_quarter(const Segment& J, unsigned flags)
+{
+    return make_uint4((unsigned)J.cur, (unsigned)J.sp | ((unsigned)J.mesh << 8) | ((unsigned)J.resume << 16) | flags, __float_as_uint(J.pend.dist),
+                      (unsigned)J.pend.rec);
+}
+
+// Write the whole job of the calling lane: the object-space ray and scale of the mesh just entered (enter_mesh), the exact distance
+// the query has resolved so far, the state quarter.
+template <int BLOCK>
+__device__ __forceinline__ void job_write(const PoolRef& Q, int slot, const Segment& J)
+{
+    ff_smem[Q.job_base + slot] = make_uint4(__float_as_uint(J.osr.ox), __float_as_uint(J.osr.oy), __float_as_uint(J.osr.oz), __float_as_uint(J.scale));
+    ff_smem[Q.job_base + BLOCK + slot] = make_uint4(__float_as_uint(J.osr.dx), __float_as_uint(J.osr.dy), __float_as_uint(J.osr.dz), __float_as_uint(J.best.dist));
+    ff_smem[Q.job_base + 2 * BLOCK + slot] = job_state_quarter(J, 0u);
+}
+
+// Pick a job up: the traversal state of trace_bvh_kernel's Segment, rebuilt from the 48 bytes (slab constants, box planes,
+// pruning bound) and the mesh's record.
+template <int BLOCK, class LDS>
+__device__ __forceinline__ void job_load(const PoolRef& Q, const LDS& L, int slot, Segment& J)
+{
+    const uint4 a = ff_smem[Q.job_base + slot], b = ff_smem[Q.job_base + BLOCK + slot], c = ff_smem[Q.job_base + 2 * BLOCK + slot];
+    J.osr.ox = __uint_as_float(a.x); J.osr.oy = __uint_as_float(a.y); J.osr.oz = __uint_as_float(a.z);
+    J.scale = __uint_as_float(a.w);
+    J.osr.dx = __uint_as_float(b.x); J.osr.dy = __uint_as_float(b.y); J.osr.dz = __uint_as_float(b.z);
+    J.best.dist = __uint_as_float(b.w);
+    J.best.geom = -1;
+    J.best.rec = -1;
+    J.cur = (int)c.x;
+    J.sp = (int)(c.y & 0xFFu);
+    J.mesh = (int)((c.y >> 8) & 0xFFu);
+    J.resume = (int)((c.y >> 16) & 0x3FFFu); // (> 0: the leaf under the cursor continues from triangle resume - 1: leaf_step)
+    J.pend.dist = __uint_as_float(c.z);
+    J.pend.rec = (int)c.w;
+    J.pend.geom = (int)c.w == kPendEmpty ? -1 : J.mesh; // (only its sign matters to offer(); the owner knows whose it is)
+    J.meshes = 0u;
+    J.tl_sp = 0;
+    J.ix = safe_rcp(J.osr.dx);
+    J.iy = safe_rcp(J.osr.dy);
+    J.iz = safe_rcp(J.osr.dz);
+    J.ox = -J.osr.ox * J.ix;
+    J.oy = -J.osr.oy * J.iy;
+    J.oz = -J.osr.oz * J.iz;
+    set_box_planes(L, J);
+    refresh_tbound(J);
+    const int4 tree = lds_geom_i4(L, J.mesh, 17);
+    J.node_base = tree.z;
+    J.lds_count = tree.w;
+    J.lds_first = __float_as_int(lds_geom4(L, J.mesh, 14).w);
+}
+
+// One time slice of the traverse role: inner-node phases and leaf phases alternate wave-wide (traverse_budget without the parts
+// that belong to the owner: mesh entry and exact resolution) until `limit` inner rounds have been spent or no lane can go on.
+// A lane is busy while its cursor is on a node or a leaf and no near tie is waiting for its owner (`tied`: leaf_step left the leaf
+// under the cursor with J.resume set).
+template <bool STATS, class LDS>
+__device__ __forceinline__ void pool_slice(const LDS& L, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, Segment& J, bool& tied,
+                                           Counters& cnt, int limit, int leaf_threshold)
+{
+    const Ray none = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
+    int rounds = 0;
+    for (int guard = 0; guard < 4 * kWave; ++guard) {
+        unsigned long long tb = 0, tc = 0;
+        if (STATS) tb = __builtin_amdgcn_s_memtime();
+        const bool busy = J.cur != kDone && !tied;
+        if (__ballot(busy) == 0ull) break;
+        for (;;) {
+            const bool inner = !tied && (unsigned)J.cur < (unsigned)kMeshDone;
+            if (__ballot(inner) == 0ull) break;
+            const bool tri_leaf = !tied && J.cur < 0;
+            if (__popcll(__ballot(tri_leaf)) >= leaf_threshold) break;
+            if (rounds >= limit) break;
+            ++rounds;
+            if (inner) inner_step<STATS>(L, nodes4, J, cnt);
+        }
+        if (STATS) tc = __builtin_amdgcn_s_memtime();
+        if (!tied && J.cur < 0) {
+            leaf_step<STATS>(L, tris, nodes4, none, J, cnt);
+            tied = J.resume > 0;
+        }
+        if (STATS) {
+            const unsigned long long td = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { cnt.t_inner += tc - tb; cnt.t_leaf += td - tc; }
+        }
+        if (rounds >= limit) break;
+    }
+}
+
+// The traverse role of trace_pool_kernel: take jobs from the workgroup's queue, walk them in slices, hand finished ones back, take
+// new ones as lanes fall free; leave when enough of the wave's own lanes are ready for a setup pass (`waiting`: this lane has a job
+// out; `nojob_ready`: it is ready without one) or when there is nothing to walk.  Returns true if a wait ran into the watchdog.
+//
+// A function of its own, NOT inlined, on purpose.  Walking needs every register a wave has at four waves per SIMD (128); inlined,
+// the register allocator treats the kernel's two bodies - setup pass and traversal - as one, holds three dozen values of the one
+// through the other and spills inside the loops of both (first build: 154 spills, the frame 41 % SLOWER than the lane-owned
+// kernel).  Behind a call the walk gets an allocation of its own; what the kernel holds across the call is a few flags.  Its
+// wave-uniform inputs come through a pointer to the kernel arguments and are made scalar on entry.
+template <bool STATS, int BLOCK>
+__device__ __attribute__((noinline)) bool pool_role(int job_base_in, int tid, bool waiting, bool nojob_ready, Counters* stats)
+{
+    auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni_ptr = [&](unsigned lo, unsigned hi) { return (void*)(((unsigned long long)uni(hi) << 32) | uni(lo)); };
+    const int lane = tid & (kWave - 1);
+    PoolRef Q;
+    Q.job_base = (int)uni((unsigned)job_base_in);
+    Q.ring_base = (Q.job_base + 3 * BLOCK) * 8;
+    Q.ctrl = (Q.job_base + 3 * BLOCK) * 4 + kPoolRing / 2;
+    // (the kernel left the role's wave-uniform inputs behind the queue's counters: taking the address of the kernel arguments
+    // instead would make the compiler copy all 2 KB of them into every lane's scratch memory)
+    const uint4 c0 = ff_smem[Q.ctrl / 4 + 1], c1 = ff_smem[Q.ctrl / 4 + 2], c2 = ff_smem[Q.ctrl / 4 + 3];
+    const TriRecord* tris = static_cast<const TriRecord*>(uni_ptr(c0.x, c0.y));
+    const uint4* nodes4 = static_cast<const uint4*>(uni_ptr(c0.z, c0.w));
+    int* spill = static_cast<int*>(uni_ptr(c1.x, c1.y));
+    const int slice = (int)uni(c1.z), leaf_threshold = (int)uni(c1.w), refill = (int)uni(c2.x), leave = (int)uni(c2.y), quorum = (int)uni(c2.z);
+    const unsigned layout = uni(c2.w); // lds_nodes | stack_depth << 24
+    const LdsT<0> L = make_lds<0>((int)(layout & 0xFFFFFFu), (int)(layout >> 24), BLOCK, tid, 0x7fffffff, nullptr, nullptr, 0, 0, 0, 0, spill);
+    Counters cnt = {};
+    bool stuck = false;
+    Segment J;
+    J.cur = kDone;
+    J.resume = 0;
+    J.sp = 0;
+    J.mesh = 0;
+    J.pend = { kInf, -1, kPendEmpty };
+    J.best = { kInf, -1, -1 };
+    int jslot = -1;
+    bool tied = false;
+    LdsT<0> Lj = L;
+    bool leaving = false; // enough of this wave's own lanes are ready for a setup pass: no new jobs, the held ones run on for a while
+    for (int turns = 0;; ++turns) {
+        if (turns > kPoolSpinLimit) { stuck = true; break; } // (a job that never ends: a malformed tree)
+        // free lanes take new jobs once there are enough of them (one atomic for all)
+        const int held = __popcll(__ballot(jslot >= 0));
+        if (leaving && held <= leave) {
+            // put the stragglers down (16 bytes each; another wave picks them up together with other waves' stragglers) and go
+            const bool down = jslot >= 0;
+            if (down) ff_smem[Q.job_base + 2 * BLOCK + jslot] = job_state_quarter(J, 0u);
+            pool_push(Q, lane, jslot, down);
+            break;
+        }
+        if (!leaving && (kWave - held >= refill || held == 0)) {
+            const int got = pool_pop(Q, lane, jslot < 0, stuck);
+            if (got >= 0) {
+                jslot = got;
+                Lj.stack_base = L.node_cap * (kNodeVec4 * 4) + got;
+                Lj.stack_slot = got;
+                job_load<BLOCK>(Q, Lj, got, J);
+            }
+        }
+        if (__ballot(stuck) != 0ull) { stuck = true; break; }
+        if (__ballot(jslot >= 0) == 0ull) break; // nothing held, nothing queued
+        pool_slice<STATS>(Lj, tris, nodes4, J, tied, cnt, slice, leaf_threshold);
+        // finished jobs (and jobs that met a near tie) go back to their owners
+        const bool back = jslot >= 0 && (J.cur == kDone || tied);
+        if (__ballot(back) != 0ull) {
+            if (back) {
+                // (the state first, then - in an instruction of its own - the flag its owner polls)
+                const uint4 st = job_state_quarter(J, tied ? kJobTie : 0u);
+                ff_smem[Q.job_base + 2 * BLOCK + jslot] = st;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&pool_u32()[(Q.job_base + 2 * BLOCK + jslot) * 4 + 1], st.y | kJobReturned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                jslot = -1;
+                tied = false;
+                J.cur = kDone;
+                J.resume = 0;
+            }
+        }
+        // enough of this wave's own lanes ready for a setup pass?
+        if (!leaving) {
+            bool ret2 = false;
+            if (waiting) ret2 = (__hip_atomic_load(&pool_u32()[(Q.job_base + 2 * BLOCK + tid) * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kJobReturned) != 0u;
+            leaving = __popcll(__ballot(ret2 || nojob_ready)) >= quorum;
+        }
+    }
+    if (STATS && stats != nullptr) {
+        stats->nodes += cnt.nodes; stats->tris += cnt.tris;
+        stats->inner_rounds += cnt.inner_rounds; stats->leaf_rounds += cnt.leaf_rounds; stats->tri_rounds += cnt.tri_rounds;
+        stats->stack_overflow += cnt.stack_overflow;
+        stats->t_inner += cnt.t_inner; stats->t_leaf += cnt.t_leaf;
+        stats->t_l1 += cnt.t_l1; stats->t_l2 += cnt.t_l2; stats->t_l3 += cnt.t_l3;
+    }
+    return __ballot(stuck) != 0ull;
+}
+
+template <bool STATS, int BLOCK, bool EXTRAS>
+__global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const LdsT<0> L = make_lds<0>(p.lds_nodes, p.stack_depth, BLOCK, tid, EXTRAS ? p.num_quads : 0x7fffffff, EXTRAS ? p.trinormals : nullptr, p.geoms, 0, 0, 0,
+                                  0, p.stack_spill);
+    const uint4* nodes4 = reinterpret_cast<const uint4*>(p.nodes4);
+    if (p.debug_lds_words != 0u) {
+        for (unsigned i = tid; i < p.debug_lds_words; i += BLOCK) reinterpret_cast<unsigned*>(ff_smem)[i] = p.debug_lds_pattern;
+        __syncthreads();
+    }
+    // the pool sits behind the geometry records: [jobs: 3 quarters x BLOCK x 16 B][ring: kPoolRing x 2 B][head, tail, -, -]
+    PoolRef Q;
+    Q.job_base = L.geom_base + p.num_geoms * kGeomVec4;
+    Q.ring_base = (Q.job_base + 3 * BLOCK) * 8;
+    Q.ctrl = (Q.job_base + 3 * BLOCK) * 4 + kPoolRing / 2;
+    for (int i = tid; i < kPoolRing / 2; i += BLOCK) pool_u32()[Q.ring_base / 2 + i] = 0xFFFFFFFFu;
+    if (tid < 4) pool_u32()[Q.ctrl + tid] = 0u;
+    if (tid == 0) {
+        // the traverse role's wave-uniform inputs (pool_role reads them back from here)
+        const unsigned long long a = (unsigned long long)p.tris, b = (unsigned long long)p.nodes4, c = (unsigned long long)p.stack_spill;
+        ff_smem[Q.ctrl / 4 + 1] = make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
+        ff_smem[Q.ctrl / 4 + 2] = make_uint4((unsigned)c, (unsigned)(c >> 32), (unsigned)p.pool_slice, (unsigned)p.leaf_threshold);
+        ff_smem[Q.ctrl / 4 + 3] = make_uint4((unsigned)p.pool_refill, (unsigned)p.pool_leave, (unsigned)p.pool_quorum, (unsigned)p.lds_nodes | ((unsigned)p.stack_depth << 24));
+    }
+    ff_smem[Q.job_base + 2 * BLOCK + tid] = make_uint4((unsigned)kDone, 0u, 0u, (unsigned)kPendEmpty);
+    stage_scene(L, nodes4, p.geoms, p.num_geoms, p.num_planes, tid, BLOCK); // (ends with the workgroup's barrier)
+
+    Counters cnt = {};
+    WaveQueue WQ = make_wave_queue(p);
+    // The lane's own path (Path) and what it keeps of its query while a job is out (the exactly resolved winner so far, the pending
+    // candidate, the meshes to come; its ray count) live in the lane's slot of a global array (KParams::park, 7 x 16 bytes, lane-
+    // strided) BETWEEN setup passes: a pass loads them, works, and stores them back.  While the lane walks other lanes' jobs they
+    // would be 30 registers of dead weight, and walking needs every register the wave has (four waves per SIMD: 128); carried
+    // through the loop they were spilled and re-loaded piecemeal in every phase (first build: 154 spills, -41 %).  What IS carried
+    // from iteration to iteration is a handful of flags.
+    // (`me` is the thread's index behind an optimisation barrier, taken afresh in every pass: formed from `tid` the seven slot
+    // addresses - and a dozen others - are loop invariants that the compiler computes once and then holds in registers through
+    // BOTH roles: 80 VGPRs that neither could spare)
+    auto park_slot = [&](int k, int me) { return p.park + ((size_t)k * gridDim.x + blockIdx.x) * (size_t)BLOCK + (size_t)me; };
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto park_store = [&](int me, const Path& P, const BestId& obest, const Pending& opend, unsigned omeshes, unsigned rays) {
+        *park_slot(0, me) = make_float4(__int_as_float(P.bitem), __int_as_float(P.send), __uint_as_float(P.gxy), __int_as_float(P.s));
+        *park_slot(1, me) = make_float4(__int_as_float(P.b), P.pdx, P.pdy, P.pdz);
+        *park_slot(2, me) = make_float4(P.ray.ox, P.ray.oy, P.ray.oz, P.ray.dx);
+        *park_slot(3, me) = make_float4(P.ray.dy, P.ray.dz, P.bx, P.by);
+        *park_slot(4, me) = make_float4(P.bz, P.ax, P.ay, P.az);
+        *park_slot(5, me) = make_float4(obest.dist, __int_as_float(obest.geom), __int_as_float(obest.rec), opend.dist);
+        *park_slot(6, me) = make_float4(__int_as_float(opend.geom), __int_as_float(opend.rec), __uint_as_float(omeshes), __uint_as_float(rays));
+    };
+    {
+        Path P0;
+        init_path(P0);
+        park_store(tid, P0, BestId{ kInf, -1, -1 }, Pending{ kInf, -1, -1 }, 0u, 0u);
+    }
+    bool more_meshes = false; // the lane's query has candidate meshes left (omeshes != 0)
+    bool active = false, exhausted = false, inflight = false; // inflight: the lane has a query (begun, not yet shaded)
+    bool waiting = false;                                     // ... and a job of it is out (queued, being walked, or handed back and not yet read)
+    bool cached = false;
+    auto cache_slot = [&](int k, int me) { return p.primary_cache + ((size_t)k * gridDim.x + blockIdx.x) * (size_t)BLOCK + (size_t)me; };
+    unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
+    const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
+    const int quorum = p.pool_quorum, qmin = p.pool_quorum_min;
+    int starved = 0; // consecutive polls that found nothing to do
+    // Watchdog: every loop of this kernel is bounded.  A wave that sleeps kPoolSpinLimit times in a row, or waits that long for a
+    // queue entry, gives up: it reports through the guard counter (the host turns it into an error, as for the traversal loop
+    // guard) and leaves, so a scheduling bug is a failed frame, not a hung GPU.
+    bool stuck = false;
+    int idle_polls = 0;
+    for (unsigned turns = 0;; ++turns) {
+        if (stuck || idle_polls > kPoolSpinLimit || (FF_POOL_DEBUG && turns > (1u << 16))) {
+            cnt.guard_hits |= 1ull;
+            if (FF_POOL_DEBUG) {
+                const unsigned long long bw = __ballot(waiting), bi = __ballot(inflight), ba = __ballot(active), be = __ballot(exhausted);
+                if (lane == 0)
+                    printf("pool watchdog: block %d wave %d stuck %d idle %d turns %u waiting %llx inflight %llx active %llx exhausted %llx head %u tail %u\n", (int)blockIdx.x,
+                           tid / kWave, (int)stuck, idle_polls, turns, bw, bi, ba, be, pool_u32()[Q.ctrl], pool_u32()[Q.ctrl + 1]);
+            }
+            break;
+        }
+        // ---- what can this wave do? ----
+        const int me_d = opaque(tid);
+        bool returned = false;
+        if (waiting) returned = (__hip_atomic_load(&pool_u32()[(Q.job_base + 2 * BLOCK + me_d) * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kJobReturned) != 0u;
+        const bool mine = returned || (!waiting && (inflight || active || !exhausted)); // lanes a setup pass would serve
+        const int nready = __popcll(__ballot(mine));
+        const unsigned queued = (unsigned)__builtin_amdgcn_readfirstlane((int)pool_waiting(Q));
+        const bool any_waiting = __ballot(waiting) != 0ull;
+        bool do_setup = nready >= quorum || (nready > 0 && !any_waiting && queued == 0u);
+        if (!do_setup && queued == 0u) {
+            if (nready == 0 && !any_waiting) break; // nothing left for this wave: no work, no query, no job out
+            // the queue has nothing to offer and the wave's own jobs are with other waves: serve the lanes that are ready if they are
+            // a fair number, else look again shortly (and serve whatever is there after a few empty looks: nobody may wait for ever)
+            if (nready >= qmin || (nready > 0 && starved >= 4)) do_setup = true;
+            else {
+                ++starved;
+                ++idle_polls;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+        }
+        starved = 0;
+        idle_polls = 0;
+#ifdef FF_EXP_NO_SETUP
+        if (do_setup) { active = false; exhausted = true; waiting = false; continue; }
+#endif
+        if (do_setup) {
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+            if (STATS) t0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int me = opaque(tid);
+            Path P;
+            BestId obest;
+            Pending opend;
+            unsigned omeshes;
+            {
+                const float4 a0 = *park_slot(0, me), a1 = *park_slot(1, me), a2 = *park_slot(2, me), a3 = *park_slot(3, me), a4 = *park_slot(4, me), a5 = *park_slot(5, me),
+                             a6 = *park_slot(6, me);
+                P.bitem = __float_as_int(a0.x); P.send = __float_as_int(a0.y); P.gxy = __float_as_uint(a0.z); P.s = __float_as_int(a0.w);
+                P.b = __float_as_int(a1.x); P.pdx = a1.y; P.pdy = a1.z; P.pdz = a1.w;
+                P.ray.ox = a2.x; P.ray.oy = a2.y; P.ray.oz = a2.z; P.ray.dx = a2.w;
+                P.ray.dy = a3.x; P.ray.dz = a3.y; P.bx = a3.z; P.by = a3.w;
+                P.bz = a4.x; P.ax = a4.y; P.ay = a4.z; P.az = a4.w;
+                obest.dist = a5.x; obest.geom = __float_as_int(a5.y); obest.rec = __float_as_int(a5.z); opend.dist = a5.w;
+                opend.geom = __float_as_int(a6.x); opend.rec = __float_as_int(a6.y); omeshes = __float_as_uint(a6.z); cnt.rays = __float_as_uint(a6.w);
+            }
+            // -- jobs that came back: merge what they found; a near tie is resolved exactly and the job goes out again --
+            bool repost = false;
+            if (returned) {
+                const uint4 c = ff_smem[Q.job_base + 2 * BLOCK + me];
+                const int mesh = (int)((c.y >> 8) & 0xFFu);
+                if ((int)c.w >= 0) {
+                    opend.dist = __uint_as_float(c.z);
+                    opend.geom = mesh;
+                    opend.rec = (int)c.w;
+                }
+                waiting = false;
+                repost = (c.y & kJobTie) != 0u;
+            }
+            if (__ballot(repost) != 0ull) {
+                if (repost) {
+                    HitPoint H;
+                    resolve_pending(L, p.tris, P.ray, opend, obest, H);
+                    // (the job's ray, cursor, stack height and leaf position are where the walk left them; the pending slot is empty now)
+                    pool_u32()[(Q.job_base + BLOCK + me) * 4 + 3] = __float_as_uint(obest.dist);
+                    unsigned* st = &pool_u32()[(Q.job_base + 2 * BLOCK + me) * 4];
+                    st[1] = st[1] & ~(kJobReturned | kJobTie);
+                    st[2] = __float_as_uint(kInf);
+                    st[3] = (unsigned)kPendEmpty;
+                    waiting = true;
+                }
+            }
+            // Lanes whose query is complete (or that have none) resolve + shade + spawn together.
+            const bool setup = mine && !waiting && !(inflight && omeshes != 0u);
+            (void)more_meshes;
+            Best best;
+            bool hit = false;
+            bool shade_now = setup && inflight;
+            if (shade_now) {
+                Segment S;
+                S.best = obest;
+                S.pend = opend;
+                finish_segment(L, p.tris, P.ray, S, best);
+                hit = best.geom >= 0;
+            }
+            unsigned skipped = 0u;
+            if (p.primary_cache != nullptr && shade_now && P.b == 0 && !cached) {
+                *cache_slot(0, me) = make_float4(best.dist, best.px, best.py, best.pz);
+                *cache_slot(1, me) = make_float4(best.cx, best.cy, best.cz, __int_as_float(best.geom));
+                *cache_slot(2, me) = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
+                cached = true;
+                if (!hit && P.bitem >= 0) {
+                    skipped = (unsigned)(P.send - 1 - P.s);
+                    P.s = P.send - 1;
+                    if (skipped) {
+                        cnt.rays += skipped;
+                        atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + me / kWave) % kRaySlots)], (unsigned long long)skipped);
+                    }
+                }
+            }
+            bool from_cache = setup && !inflight && active && P.b == 0 && cached;
+            if (STATS) t1 = __builtin_amdgcn_s_memtime();
+            bool settle_now = shade_now, goes_on = false;
+            for (;;) {
+                if (from_cache) {
+                    const float4 c0 = *cache_slot(0, me), c1 = *cache_slot(1, me), c2 = *cache_slot(2, me);
+                    best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
+                    best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
+                    best.geom = __float_as_int(c1.w);
+                    best.rec = __float_as_int(c2.x);
+                    hit = best.geom >= 0;
+                    cnt.rays += 1;
+                    settle_now = true;
+                }
+                cnt.reused += (unsigned)__popcll(__ballot(from_cache));
+                if (__ballot(settle_now) == 0ull) break;
+                bool again = false;
+                if (settle_now) {
+                    MaterialRef M;
+                    M.global = nullptr;
+                    M.geom_base = L.geom_base;
+                    M.g = best.geom;
+                    const int r = settle_hit<EXTRAS>(p, best, hit, M, P);
+                    inflight = false;
+                    active = r != kPixelDone;
+                    goes_on = r == kGoesOn;
+                    again = r == kNewSample && cached;
+                }
+                settle_now = false;
+                from_cache = again && __popcll(__ballot(again)) >= p.reuse_quorum;
+            }
+            if (goes_on) {
+                MaterialRef M;
+                M.global = nullptr;
+                M.geom_base = L.geom_base;
+                M.g = best.geom;
+                scatter<EXTRAS>(p, best, M, P);
+            }
+            if (STATS) t2 = __builtin_amdgcn_s_memtime();
+            {
+                const bool need = setup && !active && !exhausted;
+                if (__ballot(need) != 0ull) {
+                    const bool got = acquire_pixel(p, lane, P, WQ, need, cnt.rays);
+                    if (need) {
+                        active = got;
+                        exhausted = !got;
+                        cached = false;
+                    }
+                }
+            }
+            if (STATS) t3 = __builtin_amdgcn_s_memtime();
+            // -- the next ray's query: planes first; a lane whose ray can reach a mesh enters it and posts the job --
+            Segment S;
+            S.cur = kDone;
+            bool over = false;
+            const bool begin = setup && active && !(P.b == 0 && cached);
+            if (begin) {
+                if (STATS) probe_round(cnt.segment_rounds);
+                over = begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt, p.cut_last != 0 && P.b == p.bounces - 1, p.emitter_mask);
+                cnt.rays += 1;
+                inflight = true;
+                obest = S.best;
+                opend = S.pend;
+                omeshes = S.meshes;
+            }
+            cnt.cut += (unsigned)__popcll(__ballot(over));
+            // (a query that is going on - its last job came back without a tie - enters its next candidate mesh here as well)
+            const bool enter = mine && inflight && !waiting && omeshes != 0u;
+            bool post = false;
+            if (enter) {
+                S.best = obest;
+                S.pend = opend;
+                S.meshes = omeshes;
+                S.cur = kDone;
+                S.resume = 0;
+                while (S.cur == kDone && S.meshes != 0u) start_next_mesh(L, P.ray, S);
+                omeshes = S.meshes;
+                if (S.cur != kDone) {
+                    // (the pending candidate's identity stays here: the job only needs to know that there is one, and how far)
+                    S.pend.rec = opend.geom >= 0 ? kPendOwner : kPendEmpty;
+                    S.sp = 0;
+                    job_write<BLOCK>(Q, me, S);
+                    post = true;
+                    waiting = true;
+                }
+            }
+            pool_push(Q, lane, me, post || repost);
+            more_meshes = omeshes != 0u;
+            park_store(me, P, obest, opend, omeshes, cnt.rays);
+            if (STATS) {
+                t4 = __builtin_amdgcn_s_memtime();
+                tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3;
+            }
+            continue;
+        }
+
+        // ---- the traverse role (a function of its own: see pool_role) ----
+        {
+            unsigned long long t4 = 0;
+            if (STATS) t4 = __builtin_amdgcn_s_memtime();
+            const int me_r = opaque(tid);
+            const bool nojob_ready = !waiting && (inflight || active || !exhausted);
+            if (pool_role<STATS, BLOCK>(Q.job_base, me_r, waiting, nojob_ready, STATS ? &cnt : nullptr)) stuck = true;
+            if (STATS) tphase[4] += __builtin_amdgcn_s_memtime() - t4;
+        }
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&p.counters[4], tphase[0]);
+        atomicAdd(&p.counters[5], tphase[1]);
+        atomicAdd(&p.counters[6], tphase[2]);
+        atomicAdd(&p.counters[7], tphase[3]);
+        atomicAdd(&p.counters[13], tphase[4]);
+        atomicMax(&p.counters[22], tphase[0] + tphase[1] + tphase[2] + tphase[3] + tphase[4]);
+        atomicMax(&p.counters[24], ~(unsigned long long)wave_t0);
+        atomicMax(&p.counters[25], (unsigned long long)wall_clock64());
+    }
+    flush_counters(p, lane, cnt, STATS);
+}
+
 // ---- the brute-force mega-kernel (reference loop, validation path) ---------------------------------------------------
 
 template <bool STATS>
@@ -2397,6 +2997,12 @@ __global__ void unpack_strips_kernel(const unsigned char* __restrict__ src, unsi
 
 } // namespace
 
+#ifdef FF_PROBE
+// Register-pressure probes (tools/diag/probe_kernel.sh): compile ONE instantiation to ISA in a few seconds.
+namespace {
+template __global__ void FF_PROBE(const KParams);
+}
+#else
 // (num_geoms: the records cached in LDS; 0 for scenes of more than 32 geometries, whose records stay in global memory)
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms)
 {
@@ -2404,9 +3010,9 @@ size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_
            (size_t)num_geoms * sizeof(GeomRecord);
 }
 
-int max_lds_nodes(int stack_depth, int block_threads, int num_geoms)
+int max_lds_nodes(int stack_depth, int block_threads, int num_geoms, size_t reserve)
 {
-    const long avail = (long)kLdsBudgetBytes - (long)stack_depth * (long)block_threads * (long)sizeof(unsigned) -
+    const long avail = (long)kLdsBudgetBytes - (long)reserve - (long)stack_depth * (long)block_threads * (long)sizeof(unsigned) -
                        (long)num_geoms * (long)sizeof(GeomRecord);
     return avail > 0 ? (int)(avail / (long)sizeof(Bvh4Node)) : 0;
 }
@@ -2443,6 +3049,18 @@ hipError_t prepare_kernels()
     FF_SET_LDS((trace_bvh_kernel<true, 768, true, 2>))
     FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 2>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, true, 2>))
+    FF_SET_LDS((trace_pool_kernel<false, 512, false>))
+    FF_SET_LDS((trace_pool_kernel<false, 512, true>))
+    FF_SET_LDS((trace_pool_kernel<true, 512, false>))
+    FF_SET_LDS((trace_pool_kernel<true, 512, true>))
+    FF_SET_LDS((trace_pool_kernel<false, 768, false>))
+    FF_SET_LDS((trace_pool_kernel<false, 768, true>))
+    FF_SET_LDS((trace_pool_kernel<true, 768, false>))
+    FF_SET_LDS((trace_pool_kernel<true, 768, true>))
+    FF_SET_LDS((trace_pool_kernel<false, 1024, false>))
+    FF_SET_LDS((trace_pool_kernel<false, 1024, true>))
+    FF_SET_LDS((trace_pool_kernel<true, 1024, false>))
+    FF_SET_LDS((trace_pool_kernel<true, 1024, true>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH, 1>))
     FF_SET_LDS((ray_batch_kernel<FF_TRACE_BVH, 2>))
@@ -2450,12 +3068,32 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
+size_t pool_lds_bytes(int block_threads) { return (size_t)block_threads * 48 + (size_t)kPoolRing * 2 + 64; } // jobs, ring, [head, tail, -, -], the role's inputs
+
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
-                        const char** kernel_name)
+                        const char** kernel_name, bool pool)
 {
     const dim3 grid(grid_blocks);
     const char* name = "";
-    if (trace_mode == FF_TRACE_BVH) {
+    if (trace_mode == FF_TRACE_BVH && pool && p.num_geoms <= kChunkGeometries) {
+        const dim3 block(block_threads);
+        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms) + pool_lds_bytes(block_threads);
+        const bool extras = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr;
+#define FF_LAUNCH_POOL(B)                                                                                                 \
+    do {                                                                                                                  \
+        if (collect_stats) {                                                                                              \
+            if (extras) { hipLaunchKernelGGL((trace_pool_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_pool_kernel<true, " #B ", true>"; } \
+            else { hipLaunchKernelGGL((trace_pool_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_pool_kernel<true, " #B ", false>"; } \
+        } else {                                                                                                          \
+            if (extras) { hipLaunchKernelGGL((trace_pool_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_pool_kernel<false, " #B ", true>"; } \
+            else { hipLaunchKernelGGL((trace_pool_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_pool_kernel<false, " #B ", false>"; } \
+        }                                                                                                                 \
+    } while (0)
+        if (block_threads == 1024) FF_LAUNCH_POOL(1024);
+        else if (block_threads == 768) FF_LAUNCH_POOL(768);
+        else FF_LAUNCH_POOL(512);
+#undef FF_LAUNCH_POOL
+    } else if (trace_mode == FF_TRACE_BVH) {
         const dim3 block(block_threads);
         const int big = p.num_geoms <= kChunkGeometries ? 0 : (p.num_geoms <= kMaxLdsRecords ? 1 : 2);
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, big == 2 ? 0 : p.num_geoms);
@@ -2554,4 +3192,5 @@ hipError_t launch_unpack_strips(const void* src, unsigned char* rgb8, float* rad
     return hipGetLastError();
 }
 
+#endif // FF_PROBE
 } // namespace ff

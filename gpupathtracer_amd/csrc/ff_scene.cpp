@@ -783,7 +783,7 @@ int compile_scene(const FfGeometry* geoms, int n, const BvhBuildParams& params, 
 
 namespace ff {
 size_t bvh_lds_bytes(int lds_nodes, int stack_depth, int block_threads, int num_geoms);
-int max_lds_nodes(int stack_depth, int block_threads, int num_geoms);
+int max_lds_nodes(int stack_depth, int block_threads, int num_geoms, size_t reserve = 0);
 
 namespace {
 

@@ -37,8 +37,11 @@ struct FfState {
     size_t cull_mask_bytes = 0;
     float4* d_primary_cache = nullptr; // KParams::primary_cache
     size_t primary_cache_bytes = 0;
+    float4* d_park = nullptr;          // KParams::park (job-pool kernel)
+    size_t park_bytes = 0;
     int* d_stack_spill = nullptr;         // (stack_entries - stack_lds_levels) x launch threads ints
     size_t stack_spill_bytes = 0;
+    bool use_pool = false;                    // the scene renders with the job-pool kernel (finalize_layout): its LDS layout leaves room for the pool
     int scene_block_threads = 0, lds_cap = 0; // BVH kernel workgroup size and LDS node slots chosen for this scene (finalize_layout)
     bool has_specular = false;
     uint64_t num_tris = 0;
@@ -100,7 +103,11 @@ struct FfState {
         unsigned long lds_fill_words = 0, lds_fill_pattern = 0;
         int pool = -1;                 // FF_POOL: -1 the library's choice, 0 the lane-owned traversal kernel, 1 the job-pool kernel
         int pool_quorum = 0;           // FF_POOL_QUORUM: ready lanes a wave waits for before a setup pass (0: the library's choice)
-        int pool_batch_min = 0;        // FF_POOL_BATCH_MIN: a traversal batch is handed back when fewer lanes are still busy (0: the library's choice)
+        int pool_quorum_min = 0;       // FF_POOL_QUORUM_MIN: ... when the job queue is empty
+        int pool_refill = 0;           // FF_POOL_REFILL: free lanes of a traversing wave that trigger a fetch of new jobs
+        int pool_slice = 0;            // FF_POOL_SLICE: inner-node rounds per traversal slice
+        int pool_leave = -1;           // FF_POOL_LEAVE: jobs a wave may still hold when it leaves the traverse role for a setup pass (they are put down)
+        int pool_stack_levels = 0;     // FF_POOL_STACK_LEVELS: traversal stack levels kept in LDS (the deeper ones spill)
     } sw;
     int block_threads = ff::kBlockThreadsMax; // BVH kernel workgroup size (512 or 1024); FF_BLOCK_THREADS overrides for experiments
     bool setup_threshold_forced = false;

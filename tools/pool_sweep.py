@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Same-box sweep of the trace kernels' knobs: every configuration is a set of FF_* switches (read at ff_create), rendered on one
+box in one process, the configurations interleaved `--reps` times; prints the median kernel rate of each.
+
+    pool_sweep.py [--scene c2|c3|c4] [--spp 128] [--reps 3] [--size 1920x1080] "FF_POOL=0" "FF_POOL=1" "FF_POOL=1,FF_POOL_QUORUM=48" ...
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpupathtracer_amd import lib, scenes  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="c2")
+    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--check", action="store_true", help="compare every configuration's radiance bits and ray count with the first one's")
+    ap.add_argument("configs", nargs="+")
+    a = ap.parse_args()
+    w, h = (int(v) for v in a.size.split("x"))
+    scene = {"c2": scenes.cornell_wahoo_scene, "c3": scenes.blooper_scene, "c4": scenes.sphere_stress_scene}[a.scene]()
+    cam = scenes.posed_camera(w, h, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0) if a.scene == "c3" else scenes.posed_camera(w, h, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    params = lib.render_params(w, h, a.bounces, a.spp, 1234)
+    rates = {c: [] for c in a.configs}
+    ref = None
+    touched = set()
+    for rep in range(a.reps):
+        for c in a.configs:
+            for k in touched:
+                os.environ.pop(k, None)
+            for kv in c.split(","):
+                if "=" in kv:
+                    k, v = kv.split("=", 1)
+                    os.environ[k] = v
+                    touched.add(k)
+            with lib.Tracer(0) as t:
+                t.upload_scene(scene)
+                t.render(cam, params, want_rgb8=False, want_radiance=False)  # warm-up
+                if a.check and rep == 0:
+                    _, rad = t.render(cam, params)
+                    bits = rad.view(np.uint32).copy()
+                else:
+                    t.render(cam, params, want_rgb8=False, want_radiance=False)
+                st = t.stats()
+                rates[c].append(st.rays_traced / st.kernel_ms / 1e3)
+                if a.check and rep == 0:
+                    if ref is None:
+                        ref = (bits, st.rays_traced)
+                    else:
+                        same = np.array_equal(bits, ref[0]) and st.rays_traced == ref[1]
+                        print(f"  check [{c}]: {'same bits and ray count' if same else 'DIFFERENT from the first configuration'}", flush=True)
+                name = t.kernel_name()
+            print(f"  rep {rep} [{c}] {rates[c][-1]:.0f} Mrays/s  {st.kernel_ms:.2f} ms  {name}", flush=True)
+    print(f"# {a.scene} {w}x{h} {a.bounces} bounces {a.spp} spp, median of {a.reps} interleaved runs (kernel time)")
+    base = float(np.median(rates[a.configs[0]]))
+    for c in a.configs:
+        m = float(np.median(rates[c]))
+        print(f"{m:9.0f} Mrays/s  {100.0 * (m / base - 1.0):+6.2f} %  [{c}]")
+
+
+if __name__ == "__main__":
+    main()
