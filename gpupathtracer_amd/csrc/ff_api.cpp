@@ -173,11 +173,11 @@ int finalize_layout(FfState* s)
     // per thread + the queue, taken off the node cache.  Its stacks keep a fixed few levels in LDS whether or not the trees fit
     // (kPoolStackLevels; the deeper entries go to the global spill area): with the jobs in LDS a tree of more than a few hundred
     // nodes does not fit anyway, and a level costs 36 nodes.
-    s->use_pool = s->sw.pool != 0 && s->num_geoms <= kChunkGeometries && nodes4 > 0;
+    s->use_pool = s->sw.pool > 0 && s->num_geoms <= kChunkGeometries && nodes4 > 0; // (FF_POOL=1; the library's own choice is the lane-owned kernel until the pool kernel beats it)
     constexpr int kPoolStackLevels = 5;
     const int pool_levels = std::min(s->stack_entries, s->sw.pool_stack_levels > 0 ? s->sw.pool_stack_levels : kPoolStackLevels);
     s->scene_block_threads = bvh_block_threads(s, s->block_threads, s->use_pool ? pool_levels : s->stack_entries);
-    if (s->use_pool && s->scene_block_threads == 0) {
+    if (s->use_pool && s->scene_block_threads != 1024) { // (the experiment is instantiated for 1 024 threads only)
         s->use_pool = false;
         s->scene_block_threads = bvh_block_threads(s, s->block_threads, s->stack_entries);
     }
@@ -204,7 +204,8 @@ int finalize_layout(FfState* s)
             if (max_lds_nodes(levels, block, lds_records(s)) >= want) s->stack_lds_levels = levels;
         }
     }
-    const int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_lds_levels, block, lds_records(s), reserve)) : 0;
+    int cap = s->scene_block_threads > 0 ? std::max(0, max_lds_nodes(s->stack_lds_levels, block, lds_records(s), reserve)) : 0;
+    if (s->sw.lds_node_cap >= 0) cap = std::min(cap, s->sw.lds_node_cap); // FF_DEBUG_LDS_NODE_CAP: experiments on partial residency
     s->lds_cap = std::min(cap, nodes4 + s->top_count);
     // the geometry tree first (every query of a big scene starts there), the meshes share the rest
     s->top_lds_count = std::min(s->top_count, cap);
@@ -435,6 +436,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.pool_refill = s->sw.pool_refill > 0 ? s->sw.pool_refill : 16;
     k.pool_slice = s->sw.pool_slice > 0 ? s->sw.pool_slice : 4;
     k.pool_leave = s->sw.pool_leave >= 0 ? s->sw.pool_leave : 24;
+    k.pool_batch_min = s->sw.pool_batch_min > 0 ? s->sw.pool_batch_min : 48;
     // (instrumented launches with a timeline run the lane-owned kernel, which keeps it; the LDS layout serves both)
     const bool pool = s->use_pool && prm->trace_mode == FF_TRACE_BVH && !(s->collect_stats && s->timeline_bucket_us > 0);
     if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !s->sw.no_primary_reuse) {
@@ -640,6 +642,8 @@ void read_switches(FfState* s)
     if (const char* e = std::getenv("FF_POOL_QUORUM_MIN")) w.pool_quorum_min = std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("FF_POOL_REFILL")) w.pool_refill = std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("FF_POOL_SLICE")) w.pool_slice = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("FF_POOL_BATCH_MIN")) w.pool_batch_min = std::max(1, std::min(1024, std::atoi(e)));
+    if (const char* e = std::getenv("FF_DEBUG_LDS_NODE_CAP")) w.lds_node_cap = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("FF_POOL_LEAVE")) w.pool_leave = std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("FF_POOL_STACK_LEVELS")) w.pool_stack_levels = std::max(1, std::min(64, std::atoi(e)));
     s->sw = w;

@@ -97,7 +97,7 @@ struct KParams {
     // Job-pool kernel (trace_pool_kernel): a wave runs a setup pass when pool_quorum of its lanes are ready for one (pool_quorum_min
     // when the job queue is empty), takes new jobs when pool_refill of its lanes are free, traverses in slices of pool_slice inner rounds
     float4* park; // 7 float4 per thread of the launch, lane-strided: where a lane's own path and query state waits while the lane walks other lanes' jobs
-    int pool_quorum, pool_quorum_min, pool_refill, pool_slice, pool_leave; // pool_leave: a wave that wants to leave the traverse role puts its jobs down once it holds no more than this many
+    int pool_quorum, pool_quorum_min, pool_refill, pool_slice, pool_leave, pool_batch_min; // pool_leave: a wave that wants to leave the traverse role puts its jobs down once it holds no more than this many
     // debugging (FF_DEBUG_TIMELINE_US=bucket): instrumented launches count the rays that complete in each bucket of the launch's
     // wall clock (100 MHz ticks since the first wave started; counters[27] holds that epoch), kTimelineBuckets buckets
     unsigned* timeline;

@@ -2174,6 +2174,12 @@ constexpr int kPendOwner = -3;           // ... holds one whose identity stays w
 constexpr unsigned kJobReturned = 0x80000000u; // job word 9 (sp | mesh << 8 | resume << 16): set by the wave that hands the job back
 constexpr unsigned kJobTie = 0x40000000u;      // ... because triangle resume - 1 of the leaf under the cursor met a near tie with the pending candidate
 
+// Wave-uniform tallies of the traverse role, kept by every build (scalar registers): how full its rounds run.
+struct PoolOccupancy {
+    unsigned inner_rounds, inner_lanes; // inner-node rounds of the wave, and the lanes that visited a node in them (= node visits)
+    unsigned leaf_rounds, leaf_lanes;   // leaf phases, and the lanes that held a leaf in them
+};
+
 struct PoolRef {
     int job_base;  // uint4 index: quarter q of job j at job_base + q * BLOCK + j
     int ring_base; // 16-bit index of ring entry 0
@@ -2307,7 +2313,7 @@ __device__ __forceinline__ void job_load(const PoolRef& Q, const LDS& L, int slo
 // under the cursor with J.resume set).
 template <bool STATS, class LDS>
 __device__ __forceinline__ void pool_slice(const LDS& L, const TriRecord* __restrict__ tris, const uint4* __restrict__ nodes4, Segment& J, bool& tied,
-                                           Counters& cnt, int limit, int leaf_threshold)
+                                           Counters& cnt, int limit, int leaf_threshold, PoolOccupancy& occ)
 {
     const Ray none = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     int rounds = 0;
@@ -2323,9 +2329,15 @@ __device__ __forceinline__ void pool_slice(const LDS& L, const TriRecord* __rest
             if (__popcll(__ballot(tri_leaf)) >= leaf_threshold) break;
             if (rounds >= limit) break;
             ++rounds;
+            if (!STATS) { occ.inner_rounds += 1u; occ.inner_lanes += (unsigned)__popcll(__ballot(inner)); }
             if (inner) inner_step<STATS>(L, nodes4, J, cnt);
         }
         if (STATS) tc = __builtin_amdgcn_s_memtime();
+        if (!STATS) {
+            const unsigned at_leaf = (unsigned)__popcll(__ballot(!tied && J.cur < 0));
+            occ.leaf_rounds += at_leaf ? 1u : 0u;
+            occ.leaf_lanes += at_leaf;
+        }
         if (!tied && J.cur < 0) {
             leaf_step<STATS>(L, tris, nodes4, none, J, cnt);
             tied = J.resume > 0;
@@ -2367,6 +2379,7 @@ __device__ __attribute__((noinline)) bool pool_role(int job_base_in, int tid, bo
     const unsigned layout = uni(c2.w); // lds_nodes | stack_depth << 24
     const LdsT<0> L = make_lds<0>((int)(layout & 0xFFFFFFu), (int)(layout >> 24), BLOCK, tid, 0x7fffffff, nullptr, nullptr, 0, 0, 0, 0, spill);
     Counters cnt = {};
+    PoolOccupancy occ = { 0u, 0u, 0u, 0u };
     bool stuck = false;
     Segment J;
     J.cur = kDone;
@@ -2390,7 +2403,7 @@ __device__ __attribute__((noinline)) bool pool_role(int job_base_in, int tid, bo
             pool_push(Q, lane, jslot, down);
             break;
         }
-        if (!leaving && (kWave - held >= refill || held == 0)) {
+        if (!leaving && (kWave - held >= refill || held == 0) && (held == 0 || uni(pool_waiting(Q)) != 0u)) {
             const int got = pool_pop(Q, lane, jslot < 0, stuck);
             if (got >= 0) {
                 jslot = got;
@@ -2401,7 +2414,7 @@ __device__ __attribute__((noinline)) bool pool_role(int job_base_in, int tid, bo
         }
         if (__ballot(stuck) != 0ull) { stuck = true; break; }
         if (__ballot(jslot >= 0) == 0ull) break; // nothing held, nothing queued
-        pool_slice<STATS>(Lj, tris, nodes4, J, tied, cnt, slice, leaf_threshold);
+        pool_slice<STATS>(Lj, tris, nodes4, J, tied, cnt, slice, leaf_threshold, occ);
         // finished jobs (and jobs that met a near tie) go back to their owners
         const bool back = jslot >= 0 && (J.cur == kDone || tied);
         if (__ballot(back) != 0ull) {
@@ -2423,6 +2436,14 @@ __device__ __attribute__((noinline)) bool pool_role(int job_base_in, int tid, bo
             if (waiting) ret2 = (__hip_atomic_load(&pool_u32()[(Q.job_base + 2 * BLOCK + tid) * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kJobReturned) != 0u;
             leaving = __popcll(__ballot(ret2 || nojob_ready)) >= quorum;
         }
+    }
+    if (!STATS && lane == 0) {
+        // (the workgroup's tallies sit behind the role's inputs; thread 0 adds them to the launch's counters when the workgroup ends)
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(&pool_u32()[Q.ctrl + 16]);
+        __hip_atomic_fetch_add(&t[0], (unsigned long long)occ.inner_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&t[1], (unsigned long long)occ.inner_lanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&t[2], (unsigned long long)occ.leaf_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&t[3], (unsigned long long)occ.leaf_lanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (STATS && stats != nullptr) {
         stats->nodes += cnt.nodes; stats->tris += cnt.tris;
@@ -2453,6 +2474,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     Q.ctrl = (Q.job_base + 3 * BLOCK) * 4 + kPoolRing / 2;
     for (int i = tid; i < kPoolRing / 2; i += BLOCK) pool_u32()[Q.ring_base / 2 + i] = 0xFFFFFFFFu;
     if (tid < 4) pool_u32()[Q.ctrl + tid] = 0u;
+    if (tid < 16) pool_u32()[Q.ctrl + 16 + tid] = 0u; // the workgroup's tallies (pool_role, and the waves' time split below)
     if (tid == 0) {
         // the traverse role's wave-uniform inputs (pool_role reads them back from here)
         const unsigned long long a = (unsigned long long)p.tris, b = (unsigned long long)p.nodes4, c = (unsigned long long)p.stack_spill;
@@ -2504,6 +2526,10 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     // guard) and leaves, so a scheduling bug is a failed frame, not a hung GPU.
     bool stuck = false;
     int idle_polls = 0;
+    // where the wave's time goes (every build: three stamps per turn of the loop, scalar): setup passes, the traverse role, the rest
+    // (deciding, waiting); raw counters [16] [17] [18] and the number of setup passes / role visits in [11] [12]
+    unsigned long long tw_setup = 0ull, tw_role = 0ull, tw_rest = 0ull, tw_mark = __builtin_amdgcn_s_memtime();
+    unsigned n_setup = 0u, n_role = 0u;
     for (unsigned turns = 0;; ++turns) {
         if (stuck || idle_polls > kPoolSpinLimit || (FF_POOL_DEBUG && turns > (1u << 16))) {
             cnt.guard_hits |= 1ull;
@@ -2523,16 +2549,21 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
         const int nready = __popcll(__ballot(mine));
         const unsigned queued = (unsigned)__builtin_amdgcn_readfirstlane((int)pool_waiting(Q));
         const bool any_waiting = __ballot(waiting) != 0ull;
+        // What to do next.  A setup pass when enough lanes are ready for one; else a visit to the queue when it holds a batch worth
+        // taking (pool_batch_min jobs: a wave that takes a handful walks them on a handful of lanes - and the inner-node phase is
+        // back where the lane-owned kernel had it); else a setup pass for a smaller company (pool_quorum_min); else wait a moment
+        // for the other waves to post or hand back - and after a few empty looks take whatever there is, ready lanes first, so that
+        // nothing waits for ever.
         bool do_setup = nready >= quorum || (nready > 0 && !any_waiting && queued == 0u);
-        if (!do_setup && queued == 0u) {
-            if (nready == 0 && !any_waiting) break; // nothing left for this wave: no work, no query, no job out
-            // the queue has nothing to offer and the wave's own jobs are with other waves: serve the lanes that are ready if they are
-            // a fair number, else look again shortly (and serve whatever is there after a few empty looks: nobody may wait for ever)
+        bool do_role = !do_setup && queued >= (unsigned)p.pool_batch_min;
+        if (!do_setup && !do_role) {
+            if (nready == 0 && !any_waiting && queued == 0u) break; // nothing left for this wave: no work, no query, no job out, nothing to walk
             if (nready >= qmin || (nready > 0 && starved >= 4)) do_setup = true;
+            else if (queued > 0u && starved >= 4) do_role = true;
             else {
                 ++starved;
                 ++idle_polls;
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(4);
                 continue;
             }
         }
@@ -2541,6 +2572,11 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
 #ifdef FF_EXP_NO_SETUP
         if (do_setup) { active = false; exhausted = true; waiting = false; continue; }
 #endif
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tw_rest += now - tw_mark;
+            tw_mark = now;
+        }
         if (do_setup) {
             unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
             if (STATS) t0 = __builtin_amdgcn_s_memtime();
@@ -2708,6 +2744,12 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                 t4 = __builtin_amdgcn_s_memtime();
                 tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3;
             }
+            {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                tw_setup += now - tw_mark;
+                tw_mark = now;
+                n_setup += 1u;
+            }
             continue;
         }
 
@@ -2719,6 +2761,12 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
             const bool nojob_ready = !waiting && (inflight || active || !exhausted);
             if (pool_role<STATS, BLOCK>(Q.job_base, me_r, waiting, nojob_ready, STATS ? &cnt : nullptr)) stuck = true;
             if (STATS) tphase[4] += __builtin_amdgcn_s_memtime() - t4;
+            {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                tw_role += now - tw_mark;
+                tw_mark = now;
+                n_role += 1u;
+            }
         }
     }
     if (STATS && lane == 0) {
@@ -2732,6 +2780,30 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
         atomicMax(&p.counters[25], (unsigned long long)wall_clock64());
     }
     flush_counters(p, lane, cnt, STATS);
+    if (!STATS && lane == 0) {
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(&pool_u32()[Q.ctrl + 16]);
+        __hip_atomic_fetch_add(&t[4], tw_setup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&t[5], tw_role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&t[6], tw_rest + (__builtin_amdgcn_s_memtime() - tw_mark), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&t[7], (unsigned long long)n_setup | ((unsigned long long)n_role << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (!STATS) {
+        // node visits and round counts of the production kernel (the instrumented build counts them per lane): raw counters [1], [8],
+        // [9] and, for the lanes that held a leaf in a leaf phase, [14]
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long* t = reinterpret_cast<const unsigned long long*>(&pool_u32()[Q.ctrl + 16]);
+            atomicAdd(&p.counters[8], t[0]);
+            atomicAdd(&p.counters[1], t[1]);
+            atomicAdd(&p.counters[9], t[2]);
+            atomicAdd(&p.counters[14], t[3]);
+            atomicAdd(&p.counters[16], t[4]);
+            atomicAdd(&p.counters[17], t[5]);
+            atomicAdd(&p.counters[18], t[6]);
+            atomicAdd(&p.counters[11], t[7] & 0xFFFFFFFFull);
+            atomicAdd(&p.counters[12], t[7] >> 32);
+        }
+    }
 }
 
 // ---- the brute-force mega-kernel (reference loop, validation path) ---------------------------------------------------
@@ -3049,14 +3121,6 @@ hipError_t prepare_kernels()
     FF_SET_LDS((trace_bvh_kernel<true, 768, true, 2>))
     FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 2>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, true, 2>))
-    FF_SET_LDS((trace_pool_kernel<false, 512, false>))
-    FF_SET_LDS((trace_pool_kernel<false, 512, true>))
-    FF_SET_LDS((trace_pool_kernel<true, 512, false>))
-    FF_SET_LDS((trace_pool_kernel<true, 512, true>))
-    FF_SET_LDS((trace_pool_kernel<false, 768, false>))
-    FF_SET_LDS((trace_pool_kernel<false, 768, true>))
-    FF_SET_LDS((trace_pool_kernel<true, 768, false>))
-    FF_SET_LDS((trace_pool_kernel<true, 768, true>))
     FF_SET_LDS((trace_pool_kernel<false, 1024, false>))
     FF_SET_LDS((trace_pool_kernel<false, 1024, true>))
     FF_SET_LDS((trace_pool_kernel<true, 1024, false>))
@@ -3068,14 +3132,14 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
-size_t pool_lds_bytes(int block_threads) { return (size_t)block_threads * 48 + (size_t)kPoolRing * 2 + 64; } // jobs, ring, [head, tail, -, -], the role's inputs
+size_t pool_lds_bytes(int block_threads) { return (size_t)block_threads * 48 + (size_t)kPoolRing * 2 + 128; } // jobs, ring, [head, tail, -, -], the role's inputs, the workgroup's tallies
 
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
                         const char** kernel_name, bool pool)
 {
     const dim3 grid(grid_blocks);
     const char* name = "";
-    if (trace_mode == FF_TRACE_BVH && pool && p.num_geoms <= kChunkGeometries) {
+    if (trace_mode == FF_TRACE_BVH && pool && p.num_geoms <= kChunkGeometries && block_threads == 1024) {
         const dim3 block(block_threads);
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms) + pool_lds_bytes(block_threads);
         const bool extras = p.num_planes > p.num_quads || p.has_specular != 0 || p.trinormals != nullptr;
@@ -3089,9 +3153,7 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
             else { hipLaunchKernelGGL((trace_pool_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_pool_kernel<false, " #B ", false>"; } \
         }                                                                                                                 \
     } while (0)
-        if (block_threads == 1024) FF_LAUNCH_POOL(1024);
-        else if (block_threads == 768) FF_LAUNCH_POOL(768);
-        else FF_LAUNCH_POOL(512);
+        FF_LAUNCH_POOL(1024); // (an experiment: only the workgroup size the production kernel runs is instantiated)
 #undef FF_LAUNCH_POOL
     } else if (trace_mode == FF_TRACE_BVH) {
         const dim3 block(block_threads);

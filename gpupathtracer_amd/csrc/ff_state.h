@@ -106,6 +106,8 @@ struct FfState {
         int pool_quorum_min = 0;       // FF_POOL_QUORUM_MIN: ... when the job queue is empty
         int pool_refill = 0;           // FF_POOL_REFILL: free lanes of a traversing wave that trigger a fetch of new jobs
         int pool_slice = 0;            // FF_POOL_SLICE: inner-node rounds per traversal slice
+        int pool_batch_min = 0;        // FF_POOL_BATCH_MIN: jobs the queue must hold before a wave goes and takes some (fewer only after a few empty looks)
+        int lds_node_cap = -1;         // FF_DEBUG_LDS_NODE_CAP: at most this many tree nodes in LDS (experiments on partial residency)
         int pool_leave = -1;           // FF_POOL_LEAVE: jobs a wave may still hold when it leaves the traverse role for a setup pass (they are put down)
         int pool_stack_levels = 0;     // FF_POOL_STACK_LEVELS: traversal stack levels kept in LDS (the deeper ones spill)
     } sw;

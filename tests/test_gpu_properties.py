@@ -594,3 +594,49 @@ def test_wall_pairs_and_wall_table_do_not_change_a_bit(monkeypatch):
         for a, b in zip(frames[None], frames[knob]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), knob
     assert frames[None][0].max() > 0
+
+
+def test_job_pool_kernel_equals_the_lane_owned_kernel(monkeypatch):
+    """FF_POOL=1 (csrc/ff_kernels.hip trace_pool_kernel, an opt-in experiment: profiles/r04_a_pool_kernel_negative.txt): the traversal
+    of a (ray, mesh) pair is a job parked in LDS that ANY wave of the workgroup walks, the path stays with its lane.  Only who walks
+    changes: same bits, same ray / answered / cut-short counts as the lane-owned kernel, with diffuse, specular and smooth-normal
+    scenes, several blocks per pixel, tail items (short frames), the normal-debug shade, a tile and the strips of a three-part
+    frame; the scheduling knobs do not change a bit either."""
+    cam = scenes.posed_camera(112, 72, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    outside = scenes.posed_camera(112, 72, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0)
+    cases = [(scenes.cornell_wahoo_scene(), cam, lib.render_params(112, 72, 8, 70, 5)),
+             (scenes.cornell_wahoo_scene(), cam, lib.render_params(112, 72, 3, 1100, 5)),
+             (scenes.cornell_wahoo_scene(), cam, lib.render_params(112, 72, 1, 1, 0, T.TRACE_BVH, T.SHADE_NORMAL_DEBUG)),
+             (scenes.cornell_glass_scene(), cam, lib.render_params(112, 72, 6, 9, 3)),
+             (scenes.cornell_spheres_scene(), cam, lib.render_params(112, 72, 5, 6, 3, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH_SMOOTH)),
+             (scenes.blooper_scene(), outside, lib.render_params(112, 72, 8, 130, 3))]
+
+    def frames(env):
+        for k in ("FF_POOL", "FF_POOL_QUORUM", "FF_POOL_SLICE", "FF_POOL_REFILL", "FF_POOL_LEAVE", "FF_POOL_BATCH_MIN", "FF_POOL_STACK_LEVELS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = []
+        with lib.Tracer(0) as t:
+            for scene, c, p in cases:
+                t.upload_scene(scene)
+                rgb8, rad = t.render(c, p)
+                st = t.stats()
+                out.append((rgb8.copy(), rad.view(np.uint32).copy(), st.rays_traced, st.rays_answered, st.rays_cut_short, t.kernel_name()))
+            t.upload_scene(cases[0][0])
+            p = lib.render_params(112, 72, 4, 3, 8)
+            tile = t.render_tile(cam, p, 28, 18, 56, 36)
+            strips = t.render_strips(cam, p, 8, 1, 3)
+            out.append((tile[0].copy(), tile[1].view(np.uint32).copy(), 0, 0, 0, ""))
+            out.append((strips[0].copy(), strips[1].view(np.uint32).copy(), 0, 0, 0, ""))
+        return out
+
+    ref = frames({"FF_POOL": "0"})
+    assert all("trace_pool" not in r[5] for r in ref)
+    for env in ({"FF_POOL": "1"}, {"FF_POOL": "1", "FF_POOL_QUORUM": "9", "FF_POOL_SLICE": "1", "FF_POOL_REFILL": "3", "FF_POOL_LEAVE": "60", "FF_POOL_BATCH_MIN": "2"},
+                {"FF_POOL": "1", "FF_POOL_QUORUM": "64", "FF_POOL_SLICE": "9", "FF_POOL_LEAVE": "0", "FF_POOL_STACK_LEVELS": "2"}):
+        got = frames(env)
+        assert all("trace_pool_kernel" in g[5] for g in got[:len(cases)]), [g[5] for g in got]
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert a[2:5] == b[2:5], (env, i, a[2:5], b[2:5])
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (env, i)

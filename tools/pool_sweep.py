@@ -29,6 +29,7 @@ def main():
     cam = scenes.posed_camera(w, h, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0) if a.scene == "c3" else scenes.posed_camera(w, h, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     params = lib.render_params(w, h, a.bounces, a.spp, 1234)
     rates = {c: [] for c in a.configs}
+    occ = {}
     ref = None
     touched = set()
     for rep in range(a.reps):
@@ -49,7 +50,9 @@ def main():
                 else:
                     t.render(cam, params, want_rgb8=False, want_radiance=False)
                 st = t.stats()
+                ctr = t.debug_counters()
                 rates[c].append(st.rays_traced / st.kernel_ms / 1e3)
+                occ[c] = (ctr[1] / max(1, 64 * ctr[8]), ctr[14] / max(1, 64 * ctr[9]), ctr[8], ctr[9], ctr[16], ctr[17], ctr[18], ctr[11], ctr[12]) if ctr[8] else None
                 if a.check and rep == 0:
                     if ref is None:
                         ref = (bits, st.rays_traced)
@@ -62,7 +65,12 @@ def main():
     base = float(np.median(rates[a.configs[0]]))
     for c in a.configs:
         m = float(np.median(rates[c]))
-        print(f"{m:9.0f} Mrays/s  {100.0 * (m / base - 1.0):+6.2f} %  [{c}]")
+        o = occ.get(c)
+        extra = f"  inner-round occupancy {o[0]:.3f} ({o[2] / 1e6:.1f} M rounds)  leaf-phase occupancy {o[1]:.3f} ({o[3] / 1e6:.1f} M)" if o else ""
+        if o and o[4] + o[5] + o[6]:
+            tot = o[4] + o[5] + o[6]
+            extra += f"  time: setup {o[4] / tot:.3f} role {o[5] / tot:.3f} rest {o[6] / tot:.3f}; cycles per setup pass {o[4] / max(1, o[7]):.0f} ({o[7] / 1e6:.2f} M), per role visit {o[5] / max(1, o[8]):.0f} ({o[8] / 1e6:.2f} M)"
+        print(f"{m:9.0f} Mrays/s  {100.0 * (m / base - 1.0):+6.2f} %  [{c}]{extra}")
 
 
 if __name__ == "__main__":

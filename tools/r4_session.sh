@@ -9,14 +9,8 @@ echo "== smoke" | tee $OUT/progress.log
 timeout -k 5 240 python tools/diag/pool_smoke.py big > $OUT/pool_smoke.log 2>&1 || { echo "smoke FAILED"; tail -30 $OUT/pool_smoke.log; exit 1; }
 tail -8 $OUT/pool_smoke.log
 echo "== A/B + sweep" | tee -a $OUT/progress.log
-timeout -k 5 600 python tools/pool_sweep.py --spp 128 --reps 3 --check \
-  "FF_POOL=0" "FF_POOL=1" \
-  "FF_POOL=1,FF_POOL_QUORUM=32" "FF_POOL=1,FF_POOL_QUORUM=48" "FF_POOL=1,FF_POOL_QUORUM=56" \
-  "FF_POOL=1,FF_POOL_SLICE=3" "FF_POOL=1,FF_POOL_SLICE=6" "FF_POOL=1,FF_POOL_SLICE=8" \
-  "FF_POOL=1,FF_POOL_REFILL=8" "FF_POOL=1,FF_POOL_REFILL=24" "FF_POOL=1,FF_POOL_REFILL=32" \
-  "FF_POOL=1,FF_POOL_LEAVE=0" "FF_POOL=1,FF_POOL_LEAVE=12" "FF_POOL=1,FF_POOL_LEAVE=40" \
-  "FF_POOL=1,FF_POOL_STACK_LEVELS=4" "FF_POOL=1,FF_POOL_STACK_LEVELS=7" "FF_POOL=1,FF_POOL_QUORUM_MIN=8" "FF_POOL=1,FF_POOL_QUORUM_MIN=32" \
-  "FF_POOL=1,FF_LEAF_THRESHOLD=12" "FF_POOL=1,FF_LEAF_THRESHOLD=28" "FF_POOL=1,FF_LEAF_THRESHOLD=40" \
+mapfile -t CONFIGS < <(grep -v '^#' ${SWEEP_FILE:-tools/r4_sweep_configs.txt})
+timeout -k 5 900 python tools/pool_sweep.py --spp 128 --reps 3 --check "${CONFIGS[@]}" \
   > $OUT/sweep_c2.log 2>&1 || { echo "sweep FAILED"; tail -30 $OUT/sweep_c2.log; exit 1; }
 grep -v "^  rep" $OUT/sweep_c2.log
 echo "== occupancy probes" | tee -a $OUT/progress.log
