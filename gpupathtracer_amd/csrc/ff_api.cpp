@@ -428,7 +428,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const uint64_t max_useful = ((uint64_t)k.pix_items * (uint64_t)num_blocks + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
     if ((uint64_t)grid > max_useful) grid = (int)max_useful;
     if (grid < 1) grid = 1;
-    k.primary_cache = nullptr;
+    k.primary_hits = nullptr;
     k.reuse_quorum = s->sw.reuse_quorum;
     // job-pool kernel: the defaults are where the same-box sweeps put them (profiles/r04_*pool_sweep*)
     k.pool_quorum = s->sw.pool_quorum > 0 ? s->sw.pool_quorum : 40;
@@ -439,11 +439,12 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     k.pool_batch_min = s->sw.pool_batch_min > 0 ? s->sw.pool_batch_min : 48;
     // (instrumented launches with a timeline run the lane-owned kernel, which keeps it; the LDS layout serves both)
     const bool pool = s->use_pool && prm->trace_mode == FF_TRACE_BVH && !(s->collect_stats && s->timeline_bucket_us > 0);
-    if (prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !s->sw.no_primary_reuse) {
-        // one slot per thread of the launch for the closest hit of its sample block's primary ray (trace_bvh_kernel)
-        const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)grid * (size_t)block_threads * sizeof(float4));
+    // Every sample of a pixel starts with the same ray (kernel.cu:200-205 has no jitter): a pre-pass traces it once per pixel and the
+    // frame's samples start from the stored hit (trace_bvh_kernel).  One slot of 3 x 16 bytes per pixel item.
+    const bool reuse = prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !s->sw.no_primary_reuse;
+    if (reuse) {
+        const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)k.pix_items * sizeof(float4));
         if (cst != FF_OK) return cst;
-        k.primary_cache = s->d_primary_cache;
     }
     k.park = nullptr;
     if (pool) {
@@ -479,6 +480,16 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         if (s->sw.queue_chunk > 0) k.queue_chunk = (unsigned)s->sw.queue_chunk;
         k.queue_counters = std::min(kQueueCountersDefault, grid);
         if (s->sw.queue_counters > 0) k.queue_counters = std::min(std::min(kQueueCounters, grid), s->sw.queue_counters);
+        // The last items of every counter's share go out exactly as asked for (acquire_pixel: no private stock at the end of a launch):
+        // one per lane of the waves that draw from the counter where items are long (sample blocks), an eighth of that where they are
+        // short (a 1-spp frame's paths: single-item requests cost an atomic each, which is what the chunks are there to avoid).
+        {
+            const int waves_per_counter = (grid * (block_threads / 64) + k.queue_counters - 1) / k.queue_counters;
+            // (measured on one box, profiles/r04_b_queue_tail.txt: long items 64 per wave; frames that drop most of their items at the
+            // queue - a camera outside the scene - lose with a long zone, every dropped item there being a request of its own: 8)
+            const int per_wave = s->sw.queue_tail >= 0 ? s->sw.queue_tail : (samples_per_item >= 16 && !cull ? 64 : 8);
+            k.queue_tail_items = (unsigned)(waves_per_counter * per_wave);
+        }
     }
     hipStream_t st = s->stream;
     // cudaMemset(pbo, 0) of kernel.cu:340: untraced pixels read 0.  With the full grid the combine pass writes every pixel
@@ -543,6 +554,31 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         k.cull_mask = s->d_cull_mask;
         // (a culled pixel's whole-block items are dropped; with a fine-grained tail its last block is still traced sample by sample)
         s->pending_culled_rays_per_pixel = (unsigned)(spp - (tail_mode ? tail_n : 0));
+    }
+    if (reuse) {
+        // The pre-pass: the same persistent kernel, one item per pixel, one primary ray each, the hit stored per pixel (settle_hit).  Its
+        // rays are not path segments of the frame: the kernel does not count them, and the work queue starts from zero again behind it.  (Always the lane-
+        // owned kernel, never instrumented: the frame's own launches are what the statistics describe.)
+        KParams kp = k;
+        kp.shade_mode = 100; // kShadePrimaryPass (ff_kernels.hip)
+        kp.primary_hits = s->d_primary_cache;
+        kp.bounces = 1;
+        kp.spp_total = 1;
+        kp.block_spp = 1;
+        kp.num_blocks = 1;
+        kp.block_begin = 0;
+        kp.block_end = 1;
+        kp.whole_blocks = 1u;
+        kp.total_items = kp.pix_items;
+        kp.tail_block = -1;
+        kp.cull_mask = nullptr; // (every pixel gets its stored hit: a culled pixel's tail items - its last block, traced sample by sample - read it too)
+        kp.cut_last = 0;
+        kp.timeline = nullptr;
+        kp.queue_chunk = 32u;
+        if (s->sw.queue_chunk > 0) kp.queue_chunk = (unsigned)s->sw.queue_chunk;
+        FF_HIP(launch_trace(kp, FF_TRACE_BVH, false, grid, block_threads, st, nullptr, false));
+        FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
+        k.primary_hits = s->d_primary_cache;
     }
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
@@ -644,6 +680,7 @@ void read_switches(FfState* s)
     if (const char* e = std::getenv("FF_POOL_SLICE")) w.pool_slice = std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("FF_POOL_BATCH_MIN")) w.pool_batch_min = std::max(1, std::min(1024, std::atoi(e)));
     if (const char* e = std::getenv("FF_DEBUG_LDS_NODE_CAP")) w.lds_node_cap = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("FF_QUEUE_TAIL")) w.queue_tail = std::max(0, std::min(4096, std::atoi(e)));
     if (const char* e = std::getenv("FF_POOL_LEAVE")) w.pool_leave = std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("FF_POOL_STACK_LEVELS")) w.pool_stack_levels = std::max(1, std::min(64, std::atoi(e)));
     s->sw = w;

@@ -32,6 +32,7 @@ struct KParams {
     unsigned whole_blocks; // sample blocks this launch hands out as whole (pixel, block) items: block_end - block_begin, minus the tail block
     unsigned total_items; // work items of this launch: pix_items x whole_blocks (+ the tail block's group items)
     unsigned queue_chunk; // items a wave takes from the work queue per atomic, at least (a few hundred samples of work)
+    unsigned queue_tail_items; // ... except the last this many of every counter's share, which go out exactly as asked for (acquire_pixel)
     unsigned pix_items;   // 64 per 8x8 pixel tile of the local image (tile padding included)
     int tiles_per_row;
     // integrator
@@ -84,8 +85,10 @@ struct KParams {
     // marks the pixels whose primary ray misses that box (bit pitem of the mask) and zeroes their block sums; the work queue drops
     // their items (acquire_pixel).  Null: no cull (camera inside; brute-force mode, which stays the reference's loop as written).
     const unsigned long long* cull_mask;
-    // Primary-hit cache (BVH mega-kernel): 3 float4 per thread of the launch, lane-strided; null: every primary ray is traced
-    float4* primary_cache;
+    // Primary hits (BVH mega-kernels): 3 float4 per pixel item, [3][pix_items] - the closest hit of every pixel's primary ray (distance and
+    // point; object-space normal and geometry; triangle record), written by the frame's pre-pass (shade_mode kShadePrimaryPass: one
+    // item per pixel) and read by every sample of the frame; null: every primary ray is traced
+    float4* primary_hits;
     int reuse_quorum; // lanes of a wave that must wait with a parked primary hit before the wave spends an extra shading pass on them
     // Last segment of a path (bounce index bounces - 1): only an emitter can still add radiance (shade_and_advance).  cut_last != 0:
     // every emitter of the scene is among the analytic records all queries screen first, bit g of emitter_mask says which; a
@@ -118,6 +121,7 @@ constexpr int kQueueCounters = 64;     // buffer size; a launch uses kQueueCount
 constexpr int kQueueCountersDefault = 16;
 constexpr int kQueueStride = 1024; // in 4-byte words
 constexpr int kQueueStripe = 64;   // items: counter c owns the stripes c, c + n, c + 2n, ... of the item range
+constexpr int kQueueTailWord = 64; // the counter of a share's last items sits this many words behind its chunk counter (another 256-byte line of the same 4 KiB)
 
 struct RayBatchParams {
     const FfRay* rays;

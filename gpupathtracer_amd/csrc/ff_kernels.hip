@@ -307,6 +307,10 @@ constexpr int kDone = 0x7fffffff;                         // traversal cursor of
 constexpr int kMeshDone = 0x7ffffffe;                     // big scenes: the current mesh is exhausted, the walk through the geometry tree resumes
 constexpr int kGeomLeaf = 0x40000000;                     // big scenes: ~link of a geometry-tree leaf = kGeomLeaf | geometry record index
 constexpr int kPackedEntry = 0x40000000;                  // stack entry that names a node and up to three of its slots (see inner_step)
+constexpr unsigned kItemPixelMask = 0x1FFFFFFu;           // Path::item: the pixel item number (the host keeps pix_items below 2^25) ...
+constexpr int kItemBlockShift = 25;                       // ... the sample block above it (at most 16 blocks per pixel) ...
+constexpr unsigned kItemTail = 0x80000000u;               // ... and the sign bit for tail items
+constexpr int kShadePrimaryPass = 100;                    // KParams::shade_mode of the pre-pass that traces every pixel's primary ray once (settle_hit)
 
 struct LdsBase {
     int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j
@@ -422,8 +426,17 @@ __device__ __forceinline__ void stack_push(const LDS& L, int sp, int v)
 template <class LDS>
 __device__ __forceinline__ int stack_pop(const LDS& L, int sp)
 {
-    if (__builtin_expect(sp < L.stack_depth, 1)) return reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride];
-    return L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + (size_t)L.stack_slot];
+    // (each load pinned inside its branch: left alone the compiler merges the LDS and the global one into a single flat_load_dword
+    // through a generic pointer, which takes the long way round for the LDS case and waits on both memory counters)
+    int v;
+    if (__builtin_expect(sp < L.stack_depth, 1)) {
+        v = reinterpret_cast<const int*>(ff_smem)[L.stack_base + sp * L.stride];
+        asm volatile("" : "+v"(v));
+    } else {
+        v = L.spill[((size_t)(sp - L.stack_depth) * gridDim.x + blockIdx.x) * (size_t)L.block + (size_t)L.stack_slot];
+        asm volatile("" : "+v"(v));
+    }
+    return v;
 }
 
 // kernel.cu:138 with the geometry record gathered from LDS by a lane-varying index (same arithmetic as object_space_ray).
@@ -1531,7 +1544,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 
 // Per-lane path state.
 struct Path {
-    int bitem;     // where this (pixel, sample block)'s sum goes: block * pix_items + tile-major pixel item
+    int item;      // pitem | block << 25 (the pixel's tile-major item number and the sample block whose sum this lane keeps: blocksums[pitem][block]);
+                   // negative (kItemTail | pitem): a tail item, whose samples are stored one by one (tail_samples[sample of the block][pitem])
     int send;      // one past the last sample of the block
     unsigned gxy;  // global pixel coordinates x | y << 16; the RNG counter is the pixel index y*W+x (kernel.cu:191)
     int s, b;      // current sample / segment
@@ -1578,7 +1592,9 @@ struct WaveQueue {
     unsigned next, end; // in the counter's own numbering (see queue_item)
     unsigned counter;   // which counter the wave draws from
     unsigned owned;     // how many items that counter owns
-    bool dry;           // it has nothing left
+    unsigned main_end;  // its items [0, main_end) go out in chunks, the last ones [main_end, owned) exactly as asked for (acquire_pixel)
+    bool in_tail;       // the chunked part has run dry: the wave draws from the tail counter
+    bool dry;           // nothing left at all
 };
 
 // The launch's items are dealt to the counters in stripes of kQueueStripe: counter c of n owns the stripes c, c + n, ... so
@@ -1599,6 +1615,8 @@ __device__ __forceinline__ WaveQueue make_wave_queue(const KParams& p)
     Q.next = Q.end = 0u;
     Q.counter = c;
     Q.owned = mine * kQueueStripe - cut;
+    Q.main_end = Q.owned - min(Q.owned, p.queue_tail_items);
+    Q.in_tail = Q.main_end == 0u;
     Q.dry = Q.owned == 0u;
     return Q;
 }
@@ -1627,17 +1645,36 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                 continue;
             }
             const int leader = __ffsll((long long)m) - 1;
-            const unsigned size = max((unsigned)__popcll(m), p.queue_chunk);
-            unsigned base = 0u;
-            if (lane == leader) base = atomicAdd(p.queue + Q.counter * kQueueStride, size);
-            base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-            if (base >= Q.owned) {
-                Q.dry = true;
-                Q.next = Q.end = Q.owned;
-                continue;
+            if (!Q.in_tail) {
+                const unsigned size = max((unsigned)__popcll(m), p.queue_chunk);
+                unsigned base = 0u;
+                if (lane == leader) base = atomicAdd(p.queue + Q.counter * kQueueStride, size);
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                if (base < Q.main_end) {
+                    Q.next = base;
+                    Q.end = min(base + size, Q.main_end);
+                } else {
+                    Q.in_tail = true;
+                }
             }
-            Q.next = base;
-            Q.end = min(base + size, Q.owned);
+            if (Q.in_tail && Q.next >= Q.end) {
+                // The LAST items of the counter's share are handed out exactly as asked for, from a counter of their own.  A chunk is
+                // the wave's private stock: it deals it to its own lanes as they fall idle, and a wave that takes 64 sample blocks when
+                // two of its lanes are idle works through the other 62 long after every other wave has run dry - the launch's dry end
+                // (an eighth of a multi-GPU rank's frame; 40 % of a 1-spp frame: tools/timeline_probe.py).  In the tail zone a wave holds
+                // nothing it has no lane for.
+                const unsigned size = (unsigned)__popcll(m);
+                unsigned base = 0u;
+                if (lane == leader) base = atomicAdd(p.queue + Q.counter * kQueueStride + kQueueTailWord, size);
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                if (Q.main_end + base >= Q.owned) {
+                    Q.dry = true;
+                    Q.next = Q.end = Q.owned;
+                    continue;
+                }
+                Q.next = Q.main_end + base;
+                Q.end = min(Q.next + size, Q.owned);
+            }
         }
         const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         const unsigned avail = Q.end - Q.next, asked = (unsigned)__popcll(m);
@@ -1686,12 +1723,12 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
                     P.gxy = (unsigned)gx | ((unsigned)gy << 16);
                     if (tail) {
                         const int first = p.tail_start[blk], past = p.tail_start[blk + 1]; // the group's samples inside the block
-                        P.bitem = ~(first * (int)p.pix_items + (int)pitem); // negative: slot of the next sample in tail_samples (sample-major)
+                        P.item = (int)(kItemTail | pitem);
                         P.s = p.tail_block * p.block_spp + first;
                         P.send = min(p.spp_total, p.tail_block * p.block_spp + past);
                     } else {
                         const int block = p.block_begin + (int)blk;
-                        P.bitem = (int)pitem * p.num_blocks + block;
+                        P.item = (int)(((unsigned)block << kItemBlockShift) | pitem);
                         P.s = block * p.block_spp;
                         P.send = min(p.spp_total, P.s + p.block_spp);
                     }
@@ -1723,6 +1760,15 @@ enum { kPixelDone = 0, kNewSample = 1, kGoesOn = 2 };
 template <bool SPECULAR = true>
 __device__ __forceinline__ int settle_hit(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
 {
+    if (p.shade_mode == kShadePrimaryPass) {
+        // The pre-pass of a frame: every pixel's primary ray, traced ONCE (kernel.cu:200-205 sends all samples of a pixel through the
+        // pixel's corner: no jitter), its closest hit stored per pixel; the frame's samples start from there (trace_bvh_kernel).
+        float4* out = p.primary_hits + ((unsigned)P.item & kItemPixelMask);
+        out[0] = make_float4(best.dist, best.px, best.py, best.pz);
+        out[p.pix_items] = make_float4(best.cx, best.cy, best.cz, __int_as_float(hit ? best.geom : -1));
+        out[2 * (size_t)p.pix_items] = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
+        return kPixelDone;
+    }
     const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
     // Radiance of the path: it is zero until the path ends on an emitter (the only light transport here), so it is not
     // carried across segments; "0 + beta*Le" of the integrator is beta*Le bit for bit.
@@ -1753,10 +1799,10 @@ __device__ __forceinline__ int settle_hit(const KParams& p, const Best& best, bo
             if (P.b != p.bounces - 1) return kGoesOn;
         }
     }
-    if (P.bitem < 0) {
-        // tail item: every sample is stored on its own; the combine pass adds the block's samples in order
-        p.tail_samples[~P.bitem] = make_float4(Lx, Ly, Lz, 0.f);
-        P.bitem -= (int)p.pix_items; // ~(slot + pix_items): the pixel's next sample
+    if (P.item < 0) {
+        // tail item: every sample is stored on its own (sample-major: [sample of the block][pixel item]); the combine pass adds the
+        // block's samples in order
+        p.tail_samples[(size_t)(P.s - p.tail_block * p.block_spp) * p.pix_items + ((unsigned)P.item & kItemPixelMask)] = make_float4(Lx, Ly, Lz, 0.f);
     } else {
         P.ax = P.ax + Lx;
         P.ay = P.ay + Ly;
@@ -1768,7 +1814,7 @@ __device__ __forceinline__ int settle_hit(const KParams& p, const Best& best, bo
         return kNewSample;
     }
     // sample block finished: its sum goes to the block buffer (the combine kernel adds a pixel's blocks in order)
-    if (P.bitem >= 0) p.blocksums[P.bitem] = make_float4(P.ax, P.ay, P.az, 0.f);
+    if (P.item >= 0) p.blocksums[(size_t)((unsigned)P.item & kItemPixelMask) * p.num_blocks + ((unsigned)P.item >> kItemBlockShift)] = make_float4(P.ax, P.ay, P.az, 0.f);
     return kPixelDone;
 }
 
@@ -1870,6 +1916,11 @@ __device__ __forceinline__ bool shade_and_advance(const KParams& p, const Best& 
 
 __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const Counters& cnt, bool stats)
 {
+    // (the pre-pass of a frame traces primary rays that are not path segments of the frame: only a tripped loop guard is reported)
+    if (p.shade_mode == kShadePrimaryPass) {
+        if (cnt.guard_hits != 0ull && lane == 0) atomicAdd(&p.counters[0], (unsigned long long)__popcll(cnt.guard_hits));
+        return;
+    }
     // wave-reduced counters, one atomic per wave and counter
     const unsigned long long rays = wave_sum((unsigned long long)cnt.rays);
     // (spread over kRaySlots addresses 128 bytes apart: thousands of waves end within microseconds of each other in a short
@@ -1913,7 +1964,7 @@ __device__ __forceinline__ void flush_counters(const KParams& p, int lane, const
 
 __device__ __forceinline__ void init_path(Path& P)
 {
-    P.bitem = 0; P.send = 0; P.gxy = 0; P.s = 0; P.b = 0;
+    P.item = 0; P.send = 0; P.gxy = 0; P.s = 0; P.b = 0;
     P.pdx = P.pdy = 0.f; P.pdz = 1.f;
     P.ray = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f };
     P.bx = P.by = P.bz = 1.f;
@@ -1975,9 +2026,14 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     S.node_base = 0; S.lds_first = 0; S.lds_count = 0; S.tl_sp = 0;
     S.bnx = S.bny = S.bnz = S.bfx = S.bfy = S.bfz = 0;
     bool active = false, exhausted = false, inflight = false; // inflight: S holds a query of this lane (finished or not)
-    bool cached = false; // this lane's slot of the primary-hit cache holds the hit of its current block's primary ray
-    // (the slot's address is formed where it is used - a few instructions - rather than held in two registers through the loop)
-    auto cache_slot = [&](int k) { return p.primary_cache + ((size_t)k * gridDim.x + blockIdx.x) * (size_t)BLOCK + (size_t)tid; };
+    // Every sample of a pixel starts with the same ray (kernel.cu:200-205: the pixel's corner, no jitter), so its closest hit is the
+    // same hit spp times over.  A pre-pass of the frame (this kernel with shade_mode kShadePrimaryPass: one item per pixel, the hit
+    // stored by settle_hit) traces it ONCE per pixel; here every sample starts from the stored hit: no query, no traversal, no
+    // resolution for the primary segment - one fifth of the headline frame's path segments.  (Rounds 3 kept the hit per lane and sample
+    // block: one traced primary ray per 64 samples and 1.6 GB of parked hits written per 1080p frame.)
+    const bool reuse = p.primary_hits != nullptr && p.shade_mode != kShadePrimaryPass; // wave-uniform
+    // (the address is formed where it is used - a few instructions - rather than held in registers through the loop)
+    auto stored_hit = [&](int k) { return p.primary_hits + (size_t)k * p.pix_items + ((unsigned)P.item & kItemPixelMask); };
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
@@ -2020,30 +2076,9 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             finish_segment(L, p.tris, P.ray, S, best);
             hit = best.geom >= 0;
         }
-        // Every sample of a pixel starts with the same ray (kernel.cu:200-205: the pixel's corner, no jitter), so the closest hit of
-        // a sample block's FIRST primary ray is the closest hit of all of them.  The lane parks it in its slot of a global array
-        // (36 bytes, lane-strided: the registers of the traversal loop are spoken for) and the block's other samples start from
-        // there: no query, no traversal, no resolution - one fifth of the headline frame's path segments.
         unsigned skipped = 0u;
-        if (p.primary_cache != nullptr && shade_now && P.b == 0 && !cached) {
-            *cache_slot(0) = make_float4(best.dist, best.px, best.py, best.pz);
-            *cache_slot(1) = make_float4(best.cx, best.cy, best.cz, __int_as_float(best.geom));
-            *cache_slot(2) = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
-            cached = true;
-            if (!hit && P.bitem >= 0) {
-                // Nothing in view: every sample of the block adds zero to its sum.  This sample becomes the block's last; the lane
-                // books the path segments of the others (each a query answered with "nothing") itself - it is rare.
-                skipped = (unsigned)(P.send - 1 - P.s);
-                P.s = P.send - 1;
-                if (skipped) {
-                    cnt.rays += skipped;
-                    atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + tid / kWave) % kRaySlots)], (unsigned long long)skipped);
-                }
-            }
-        }
-        if (STATS && p.timeline) tl_count += (unsigned)wave_sum((unsigned long long)skipped); // (the timeline counts every path segment)
-        // A lane that waits with a new sample whose primary hit is parked (see below) joins this iteration's shading.
-        bool from_cache = setup && !inflight && active && P.b == 0 && cached;
+        // A lane that waits with a new sample (it starts from the pixel's stored primary hit, see below) joins this iteration's shading.
+        bool from_cache = setup && !inflight && active && P.b == 0 && reuse;
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
         // Shading in two steps (settle_hit / scatter).  A lane whose path ended and whose next sample starts with the parked hit
         // settles again - at once if at least reuse_quorum lanes of the wave are in that position, else together with the next
@@ -2054,7 +2089,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         bool settle_now = shade_now, goes_on = false;
         for (;;) { // (every pass ends a sample of each lane in it: at most a block's samples)
             if (from_cache) {
-                const float4 c0 = *cache_slot(0), c1 = *cache_slot(1), c2 = *cache_slot(2);
+                const float4 c0 = *stored_hit(0), c1 = *stored_hit(1), c2 = *stored_hit(2);
                 best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
                 best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
                 best.geom = __float_as_int(c1.w);
@@ -2062,6 +2097,15 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 hit = best.geom >= 0;
                 cnt.rays += 1; // a path segment like any other, answered without a traversal (counted apart below)
                 settle_now = true;
+                if (!hit && P.item >= 0 && P.s < P.send - 1) {
+                    // Nothing in view: every sample of the block adds zero to its sum.  This sample becomes the block's last; the lane
+                    // books the path segments of the others (each a query answered with "nothing") itself - it is rare.
+                    const unsigned rest = (unsigned)(P.send - 1 - P.s);
+                    P.s = P.send - 1;
+                    cnt.rays += rest;
+                    skipped += rest;
+                    atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + tid / kWave) % kRaySlots)], (unsigned long long)rest);
+                }
             }
             {
                 const unsigned reused_now = (unsigned)__popcll(__ballot(from_cache));
@@ -2079,11 +2123,12 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 inflight = false;
                 active = r != kPixelDone;
                 goes_on = r == kGoesOn;
-                waiting = r == kNewSample && cached; // a new sample of the same block, its primary hit parked
+                waiting = r == kNewSample && reuse; // a new sample: it starts from the pixel's stored primary hit
             }
             settle_now = false;
             from_cache = waiting && __popcll(__ballot(waiting)) >= p.reuse_quorum;
         }
+        if (STATS && p.timeline) tl_count += (unsigned)wave_sum((unsigned long long)skipped); // (the timeline counts every path segment)
         if (goes_on) {
             MaterialRef M;
             M.global = BIG == 2 ? p.geoms + best.geom : nullptr;
@@ -2099,14 +2144,13 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 if (need) {
                     active = got;
                     exhausted = !got;
-                    cached = false; // a new block: its first primary ray is traced
                     if (STATS && exhausted) atomicMax(&p.counters[23], ~(unsigned long long)wall_clock64()); // (complemented) first lane to find the queue empty
                 }
             }
         }
         if (STATS) t3 = __builtin_amdgcn_s_memtime();
         bool over = false; // a last-bounce query that ended after the planes
-        if (setup && active && !(P.b == 0 && cached)) { // (a lane with a parked primary hit waits for the next shading pass)
+        if (setup && active && !(P.b == 0 && reuse)) { // (a lane whose sample starts from the stored primary hit waits for the next shading pass)
             if (STATS) probe_round(cnt.segment_rounds);
             over = begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt, p.cut_last != 0 && P.b == p.bounces - 1, p.emitter_mask);
             cnt.rays += 1;
@@ -2114,7 +2158,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
         }
         cnt.cut += (unsigned)__popcll(__ballot(over));
         if (STATS) t4 = __builtin_amdgcn_s_memtime();
-        if (__ballot(inflight || (active && P.b == 0 && cached)) == 0ull) break; // (a lane that waits with a parked hit still has work)
+        if (__ballot(inflight || (active && P.b == 0 && reuse)) == 0ull) break; // (a lane that waits with a stored hit still has work)
         // Time-sliced traversal: after `setup_threshold` inner-node rounds the finished lanes go and fetch new rays while the
         // long-tail lanes keep their state (per-ray traversal cost is heavy-tailed: a few rays need 10x the mean).
         if (inflight) traverse_budget<STATS>(L, p.tris, nodes4, P.ray, S, cnt, p.setup_threshold, p.leaf_threshold, p.num_planes);
@@ -2499,7 +2543,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     auto park_slot = [&](int k, int me) { return p.park + ((size_t)k * gridDim.x + blockIdx.x) * (size_t)BLOCK + (size_t)me; };
     auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
     auto park_store = [&](int me, const Path& P, const BestId& obest, const Pending& opend, unsigned omeshes, unsigned rays) {
-        *park_slot(0, me) = make_float4(__int_as_float(P.bitem), __int_as_float(P.send), __uint_as_float(P.gxy), __int_as_float(P.s));
+        *park_slot(0, me) = make_float4(__int_as_float(P.item), __int_as_float(P.send), __uint_as_float(P.gxy), __int_as_float(P.s));
         *park_slot(1, me) = make_float4(__int_as_float(P.b), P.pdx, P.pdy, P.pdz);
         *park_slot(2, me) = make_float4(P.ray.ox, P.ray.oy, P.ray.oz, P.ray.dx);
         *park_slot(3, me) = make_float4(P.ray.dy, P.ray.dz, P.bx, P.by);
@@ -2515,8 +2559,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     bool more_meshes = false; // the lane's query has candidate meshes left (omeshes != 0)
     bool active = false, exhausted = false, inflight = false; // inflight: the lane has a query (begun, not yet shaded)
     bool waiting = false;                                     // ... and a job of it is out (queued, being walked, or handed back and not yet read)
-    bool cached = false;
-    auto cache_slot = [&](int k, int me) { return p.primary_cache + ((size_t)k * gridDim.x + blockIdx.x) * (size_t)BLOCK + (size_t)me; };
+    const bool reuse = p.primary_hits != nullptr && p.shade_mode != kShadePrimaryPass; // every sample starts from its pixel's stored primary hit (trace_bvh_kernel)
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
     const int quorum = p.pool_quorum, qmin = p.pool_quorum_min;
@@ -2589,7 +2632,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
             {
                 const float4 a0 = *park_slot(0, me), a1 = *park_slot(1, me), a2 = *park_slot(2, me), a3 = *park_slot(3, me), a4 = *park_slot(4, me), a5 = *park_slot(5, me),
                              a6 = *park_slot(6, me);
-                P.bitem = __float_as_int(a0.x); P.send = __float_as_int(a0.y); P.gxy = __float_as_uint(a0.z); P.s = __float_as_int(a0.w);
+                P.item = __float_as_int(a0.x); P.send = __float_as_int(a0.y); P.gxy = __float_as_uint(a0.z); P.s = __float_as_int(a0.w);
                 P.b = __float_as_int(a1.x); P.pdx = a1.y; P.pdy = a1.z; P.pdz = a1.w;
                 P.ray.ox = a2.x; P.ray.oy = a2.y; P.ray.oz = a2.z; P.ray.dx = a2.w;
                 P.ray.dy = a3.x; P.ray.dz = a3.y; P.bx = a3.z; P.by = a3.w;
@@ -2636,27 +2679,13 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                 finish_segment(L, p.tris, P.ray, S, best);
                 hit = best.geom >= 0;
             }
-            unsigned skipped = 0u;
-            if (p.primary_cache != nullptr && shade_now && P.b == 0 && !cached) {
-                *cache_slot(0, me) = make_float4(best.dist, best.px, best.py, best.pz);
-                *cache_slot(1, me) = make_float4(best.cx, best.cy, best.cz, __int_as_float(best.geom));
-                *cache_slot(2, me) = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
-                cached = true;
-                if (!hit && P.bitem >= 0) {
-                    skipped = (unsigned)(P.send - 1 - P.s);
-                    P.s = P.send - 1;
-                    if (skipped) {
-                        cnt.rays += skipped;
-                        atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + me / kWave) % kRaySlots)], (unsigned long long)skipped);
-                    }
-                }
-            }
-            bool from_cache = setup && !inflight && active && P.b == 0 && cached;
+            bool from_cache = setup && !inflight && active && P.b == 0 && reuse;
             if (STATS) t1 = __builtin_amdgcn_s_memtime();
             bool settle_now = shade_now, goes_on = false;
             for (;;) {
                 if (from_cache) {
-                    const float4 c0 = *cache_slot(0, me), c1 = *cache_slot(1, me), c2 = *cache_slot(2, me);
+                    const float4* stored = p.primary_hits + ((unsigned)P.item & kItemPixelMask);
+                    const float4 c0 = stored[0], c1 = stored[p.pix_items], c2 = stored[2 * (size_t)p.pix_items];
                     best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
                     best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
                     best.geom = __float_as_int(c1.w);
@@ -2664,6 +2693,12 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     hit = best.geom >= 0;
                     cnt.rays += 1;
                     settle_now = true;
+                    if (!hit && P.item >= 0 && P.s < P.send - 1) { // nothing in view: the block ends with this sample (trace_bvh_kernel)
+                        const unsigned rest = (unsigned)(P.send - 1 - P.s);
+                        P.s = P.send - 1;
+                        cnt.rays += rest;
+                        atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + me / kWave) % kRaySlots)], (unsigned long long)rest);
+                    }
                 }
                 cnt.reused += (unsigned)__popcll(__ballot(from_cache));
                 if (__ballot(settle_now) == 0ull) break;
@@ -2677,7 +2712,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     inflight = false;
                     active = r != kPixelDone;
                     goes_on = r == kGoesOn;
-                    again = r == kNewSample && cached;
+                    again = r == kNewSample && reuse;
                 }
                 settle_now = false;
                 from_cache = again && __popcll(__ballot(again)) >= p.reuse_quorum;
@@ -2697,7 +2732,6 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     if (need) {
                         active = got;
                         exhausted = !got;
-                        cached = false;
                     }
                 }
             }
@@ -2706,7 +2740,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
             Segment S;
             S.cur = kDone;
             bool over = false;
-            const bool begin = setup && active && !(P.b == 0 && cached);
+            const bool begin = setup && active && !(P.b == 0 && reuse);
             if (begin) {
                 if (STATS) probe_round(cnt.segment_rounds);
                 over = begin_segment<STATS>(L, p.walls, p.geoms, p.num_geoms, p.num_planes, p.tris, P.ray, S, cnt, p.cut_last != 0 && P.b == p.bounces - 1, p.emitter_mask);

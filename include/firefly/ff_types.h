@@ -169,9 +169,10 @@ typedef struct FfStats {
     uint32_t flags;              /* FF_STATS_* bits about how the frame was scheduled */
     uint64_t scene_bytes_nodes;  /* device bytes of BVH nodes */
     uint64_t scene_bytes_tris;   /* device bytes of triangle records */
-    uint64_t rays_answered;      /* ... of rays_traced: path segments answered without a traversal - primary rays of pixels whose view of the
-                                    scene box is empty (camera outside the scene) and the repeated primary rays of a sample block (every sample
-                                    of a pixel starts with the same ray, kernel.cu:200-205); 0 in brute-force mode */
+    uint64_t rays_answered;      /* ... of rays_traced: path segments answered without a traversal - the primary segments of a frame of more than
+                                    one sample per pixel (every sample of a pixel starts with the same ray, kernel.cu:200-205: a pre-pass traces
+                                    it once per pixel, its rays are not counted) incl. those of pixels whose view of the scene box is empty
+                                    (camera outside the scene); 0 in brute-force mode */
     uint64_t rays_cut_short;     /* ... of rays_traced: last segments of paths (bounce index bounces - 1) whose query ended after the planes and
                                     spheres because no emitter was among the candidates - only an emitter can still add radiance there and
                                     every emitter of the scene is a plane or a sphere; 0 in brute-force mode */

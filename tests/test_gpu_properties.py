@@ -461,7 +461,7 @@ def test_primary_rays_that_miss_the_scene_box_are_dropped_at_the_queue(tracer, m
             assert st.rays_answered <= rays
             if st.flags & T.FF_STATS_TAIL_ITEMS and params.spp <= 64:
                 # the frame's only block went out sample by sample: nothing to drop, no mask pass; only repeated primaries count
-                assert st.rays_answered <= w * h * (params.spp - 1)
+                assert st.rays_answered <= w * h * params.spp
             assert (bvh[1] == 0).all(axis=2).mean() > 0.5  # most of the frame is background
             params.trace_mode = T.TRACE_BRUTE_FORCE
             brute = tracer.render(cam, params)
@@ -481,13 +481,35 @@ def test_primary_rays_that_miss_the_scene_box_are_dropped_at_the_queue(tracer, m
         assert np.array_equal(tile[1].view(np.uint32), full[1][h // 4:h // 4 + h // 2, w // 4:w // 4 + w // 2].view(np.uint32))
 
 
-def test_repeated_primary_rays_are_answered_from_the_block_cache(tracer, monkeypatch):
-    """Every sample of a pixel starts with the same ray (kernel.cu:200-205 has no jitter): the BVH kernel traces the primary ray of
-    a sample block once, parks its closest hit and starts the block's other samples from there (csrc/ff_kernels.hip
-    trace_bvh_kernel).  Same bits and the same number of path segments as with the cache off (FF_NO_PRIMARY_REUSE=1) and as the
-    brute-force kernel, which traces every one of them; FfStats::rays_answered counts exactly the repeated ones: samples minus
-    blocks per pixel (camera inside the box: no pixel is culled); with diffuse, mirror and glass surfaces, one bounce (every
-    path is its primary segment), partial last blocks, several launches per frame and interpolated normals."""
+def test_culled_pixels_have_a_stored_primary_hit_for_their_tail_items():
+    """A frame of a few sample blocks from a camera outside the scene: the whole-block items of the pixels that see nothing are
+    dropped at the queue, but their LAST block goes out sample by sample (fine-grained tail) and every one of those samples starts
+    from the pixel's stored primary hit - which the pre-pass must therefore have written for culled pixels too.  On a fresh state
+    (the hit buffer holds nothing from earlier frames), against the brute-force kernel."""
+    scene = scenes.cornell_wahoo_scene()
+    w, h = 200, 150
+    cam = scenes.posed_camera(w, h, position=(9.0, 4.0, 11.0), yaw=-130.0, pitch=-15.0)
+    for spp in (130, 512):
+        with lib.Tracer(0) as t:
+            t.upload_scene(scene)
+            params = lib.render_params(w, h, 4, spp, 11)
+            bvh = t.render(cam, params)
+            st = t.stats()
+            assert st.flags & T.FF_STATS_TAIL_ITEMS and st.rays_answered > 0
+            params.trace_mode = T.TRACE_BRUTE_FORCE
+            brute = t.render(cam, params)
+            assert st.rays_traced == t.stats().rays_traced
+            assert np.array_equal(bvh[0], brute[0]) and np.array_equal(bvh[1].view(np.uint32), brute[1].view(np.uint32)), spp
+
+
+def test_primary_rays_are_answered_from_the_pixel_s_stored_hit(tracer, monkeypatch):
+    """Every sample of a pixel starts with the same ray (kernel.cu:200-205 has no jitter): a pre-pass of the frame traces every
+    pixel's primary ray once and stores its closest hit per pixel; every sample of the frame starts from there (csrc/ff_kernels.hip
+    trace_bvh_kernel, settle_hit; csrc/ff_api.cpp render_enqueue).  Same bits and the same number of path segments as with the
+    reuse off (FF_NO_PRIMARY_REUSE=1) and as the brute-force kernel, which traces every one of them; FfStats::rays_answered counts
+    exactly the primary segments: one per sample (camera inside the box: no pixel is culled); with diffuse, mirror and glass
+    surfaces, one bounce (every path is its primary segment), partial last blocks, several launches per frame and interpolated
+    normals."""
     monkeypatch.setenv("FF_NO_PRIMARY_CULL", "1")  # (its pixels would count as answered as well)
     tracer.reload_switches()
     inside = scenes.posed_camera(96, 64, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
@@ -504,9 +526,9 @@ def test_repeated_primary_rays_are_answered_from_the_block_cache(tracer, monkeyp
             blocks = (spp + block_spp - 1) // block_spp
             tail = st.flags & T.FF_STATS_TAIL_ITEMS
             if not tail:
-                assert st.rays_answered == 96 * 64 * (spp - blocks), (bounces, spp, st.rays_answered)
+                assert st.rays_answered == 96 * 64 * spp, (bounces, spp, st.rays_answered, blocks)
             else:
-                assert 0 < st.rays_answered <= 96 * 64 * (spp - blocks)
+                assert 0 < st.rays_answered <= 96 * 64 * spp
             monkeypatch.setenv("FF_NO_PRIMARY_REUSE", "1")
             tracer.reload_switches()
             off = tracer.render(cam, params)
@@ -551,7 +573,9 @@ def test_last_bounce_queries_end_after_the_planes_when_no_emitter_is_held(tracer
             params = lib.render_params(96, 64, bounces, spp, 77, T.TRACE_BVH, shade)
             on = tracer.render(cam, params)
             st = tracer.stats()
-            assert (st.rays_cut_short > 0) == cuts, (bounces, spp, st.rays_cut_short)
+            # (one bounce and several samples: the only segment of every path is its primary one, answered from the pixel's stored hit -
+            # the pre-pass that stores it needs the true closest hit and cuts nothing)
+            assert (st.rays_cut_short > 0) == (cuts and not (bounces == 1 and spp > 1)), (bounces, spp, st.rays_cut_short)
             assert st.rays_cut_short <= 96 * 64 * spp  # at most one last segment per path
             monkeypatch.setenv("FF_NO_LAST_BOUNCE_CUT", "1")
             tracer.reload_switches()

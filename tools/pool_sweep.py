@@ -14,6 +14,37 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpupathtracer_amd import lib, scenes  # noqa: E402
 
 
+def isolated(a):
+    """Every run in a process of its own (the library is loaded once per process)."""
+    import json
+    import subprocess
+    rates = {c: [] for c in a.configs}
+    bits = {}
+    for rep in range(a.reps):
+        for c in a.configs:
+            env = dict(os.environ)
+            for kv in c.split(","):
+                if "=" in kv:
+                    k, v = kv.split("=", 1)
+                    env[k] = v
+            cmd = [sys.executable, os.path.abspath(__file__), "--one", "--scene", a.scene, "--spp", str(a.spp), "--bounces", str(a.bounces), "--size", a.size, "--reps", "1", c]
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = [l for l in out.stdout.splitlines() if l.startswith("ONE ")]
+            if not line:
+                print(f"  rep {rep} [{c}] FAILED: {out.stdout[-300:]} {out.stderr[-300:]}", flush=True)
+                continue
+            d = json.loads(line[0][4:])
+            rates[c].append(d["rate"])
+            bits.setdefault(c, (d["crc"], d["rays"]))
+            print(f"  rep {rep} [{c}] {d['rate']:.0f} Mrays/s  {d['ms']:.2f} ms  {d['kernel']}", flush=True)
+    print(f"# {a.scene} {a.size} {a.bounces} bounces {a.spp} spp, median of {a.reps} interleaved runs, one process each (kernel time)")
+    base = float(np.median(rates[a.configs[0]]))
+    for c in a.configs:
+        m = float(np.median(rates[c])) if rates[c] else float("nan")
+        same = "" if c == a.configs[0] or c not in bits else ("  same radiance checksum and ray count" if bits[c] == bits[a.configs[0]] else "  DIFFERENT radiance checksum or ray count")
+        print(f"{m:9.0f} Mrays/s  {100.0 * (m / base - 1.0):+6.2f} %  [{c}]{same}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="c2")
@@ -22,12 +53,27 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--check", action="store_true", help="compare every configuration's radiance bits and ray count with the first one's")
+    ap.add_argument("--isolate", action="store_true", help="one process per run: needed when a configuration names another library (FF_LIB_PATH=...)")
+    ap.add_argument("--one", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("configs", nargs="+")
     a = ap.parse_args()
+    if a.isolate:
+        return isolated(a)
     w, h = (int(v) for v in a.size.split("x"))
     scene = {"c2": scenes.cornell_wahoo_scene, "c3": scenes.blooper_scene, "c4": scenes.sphere_stress_scene}[a.scene]()
     cam = scenes.posed_camera(w, h, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0) if a.scene == "c3" else scenes.posed_camera(w, h, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     params = lib.render_params(w, h, a.bounces, a.spp, 1234)
+    if a.one:
+        import json
+        import zlib
+        c = a.configs[0]
+        with lib.Tracer(0) as t:
+            t.upload_scene(scene)
+            t.render(cam, params, want_rgb8=False, want_radiance=False)
+            _, rad = t.render(cam, params, want_rgb8=False)
+            st = t.stats()
+            print("ONE " + json.dumps({"rate": st.rays_traced / st.kernel_ms / 1e3, "ms": st.kernel_ms, "rays": int(st.rays_traced), "crc": zlib.crc32(rad.tobytes()), "kernel": t.kernel_name()}))
+        return
     rates = {c: [] for c in a.configs}
     occ = {}
     ref = None
