@@ -547,10 +547,15 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     // (... and so does the reference's own frame - one primary ray per pixel, shaded by its normal: tracing a ray that misses
     // everything costs what the mask pass costs, and the pass is a second launch: 0.089 instead of 0.064 ms at 1080p)
     cull = cull && num_blocks - (tail_mode ? 1 : 0) > 0 && !debug;
-    if (cull) {
-        const int mst = ensure_bytes((void**)&s->d_cull_mask, &s->cull_mask_bytes, ((size_t)k.pix_items / 64 + 2) * sizeof(unsigned long long));
+    // ... and where a pre-pass stores every pixel's primary hit (below), it marks the pixels that hit NOTHING in the same mask: the
+    // exact version of the box test, also for a camera inside the scene's box (an open room seen from within)
+    const bool exact_cull = reuse && !s->sw.no_primary_cull && num_blocks - (tail_mode ? 1 : 0) > 0;
+    if (cull || exact_cull) {
+        const size_t mask_bytes = ((size_t)k.pix_items / 64 + 2) * sizeof(unsigned long long);
+        const int mst = ensure_bytes((void**)&s->d_cull_mask, &s->cull_mask_bytes, mask_bytes);
         if (mst != FF_OK) return mst;
-        FF_HIP(launch_cull_mask(k, s->d_cull_mask, st));
+        if (cull) FF_HIP(launch_cull_mask(k, s->d_cull_mask, st));
+        else FF_HIP(hipMemsetAsync(s->d_cull_mask, 0, mask_bytes, st));
         k.cull_mask = s->d_cull_mask;
         // (a culled pixel's whole-block items are dropped; with a fine-grained tail its last block is still traced sample by sample)
         s->pending_culled_rays_per_pixel = (unsigned)(spp - (tail_mode ? tail_n : 0));
@@ -572,11 +577,13 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         kp.total_items = kp.pix_items;
         kp.tail_block = -1;
         kp.cull_mask = nullptr; // (every pixel gets its stored hit: a culled pixel's tail items - its last block, traced sample by sample - read it too)
+        kp.cull_mask_out = exact_cull ? s->d_cull_mask : nullptr;
+        kp.frame_blocks = num_blocks;
         kp.cut_last = 0;
         kp.timeline = nullptr;
         kp.queue_chunk = 32u;
         if (s->sw.queue_chunk > 0) kp.queue_chunk = (unsigned)s->sw.queue_chunk;
-        FF_HIP(launch_trace(kp, FF_TRACE_BVH, false, grid, block_threads, st, nullptr, false));
+        FF_HIP(launch_trace(kp, FF_TRACE_BVH, false, grid, block_threads, st, nullptr, false, /*prepass=*/true));
         FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
         k.primary_hits = s->d_primary_cache;
     }

@@ -85,6 +85,10 @@ struct KParams {
     // marks the pixels whose primary ray misses that box (bit pitem of the mask) and zeroes their block sums; the work queue drops
     // their items (acquire_pixel).  Null: no cull (camera inside; brute-force mode, which stays the reference's loop as written).
     const unsigned long long* cull_mask;
+    // ... and, in the frame's pre-pass (shade_mode kShadePrimaryPass) only: the same mask for writing - a pixel whose primary ray hits
+    // nothing gets its bit there (settle_hit) - and the number of sample blocks of the frame whose sums are zeroed for it
+    unsigned long long* cull_mask_out;
+    int frame_blocks;
     // Primary hits (BVH mega-kernels): 3 float4 per pixel item, [3][pix_items] - the closest hit of every pixel's primary ray (distance and
     // point; object-space normal and geometry; triangle record), written by the frame's pre-pass (shade_mode kShadePrimaryPass: one
     // item per pixel) and read by every sample of the frame; null: every primary ray is traced
@@ -153,7 +157,7 @@ size_t pool_lds_bytes(int block_threads);
 // *kernel_name (optional) receives the name of the instantiation launched, as rocprofv3 prints it.
 // pool: the job-pool kernel (scenes of up to kChunkGeometries geometries; the LDS layout must have left pool_lds_bytes free).
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
-                        const char** kernel_name = nullptr, bool pool = false);
+                        const char** kernel_name = nullptr, bool pool = false, bool prepass = false);
 // Sums every pixel's sample blocks in order, scales by 1/spp and writes radiance / rgb8 (row-major, coalesced).
 hipError_t launch_combine(const KParams& p, hipStream_t stream);
 // Fills mask[pix_items / 64] (see KParams::cull_mask) and zeroes the block sums of the culled pixels.

@@ -1757,16 +1757,29 @@ __device__ __forceinline__ bool acquire_pixel(const KParams& p, int lane, Path& 
 // settle_hit returns kPixelDone (the lane gives the pixel up), kNewSample (the next sample's primary ray is in P.ray) or kGoesOn
 // (scatter must follow with the same hit).  SPECULAR = false: the caller guarantees a scene without MIRROR / GLASS surfaces.
 enum { kPixelDone = 0, kNewSample = 1, kGoesOn = 2 };
-template <bool SPECULAR = true>
+template <bool SPECULAR = true, bool PREPASS = false>
 __device__ __forceinline__ int settle_hit(const KParams& p, const Best& best, bool hit, const MaterialRef& M, Path& P)
 {
-    if (p.shade_mode == kShadePrimaryPass) {
+    if constexpr (PREPASS) {
         // The pre-pass of a frame: every pixel's primary ray, traced ONCE (kernel.cu:200-205 sends all samples of a pixel through the
         // pixel's corner: no jitter), its closest hit stored per pixel; the frame's samples start from there (trace_bvh_kernel).
         float4* out = p.primary_hits + ((unsigned)P.item & kItemPixelMask);
         out[0] = make_float4(best.dist, best.px, best.py, best.pz);
         out[p.pix_items] = make_float4(best.cx, best.cy, best.cz, __int_as_float(hit ? best.geom : -1));
         out[2 * (size_t)p.pix_items] = make_float4(__int_as_float(best.rec), 0.f, 0.f, 0.f);
+        if (!hit && p.cull_mask_out != nullptr) {
+            // Nothing in view: every sample of the pixel adds zero.  Its bit goes into the mask the work queue consults (acquire_pixel:
+            // its whole-block items are dropped when they are decoded, their rays counted), its block sums are zeroed and it is counted -
+            // exactly what cull_mask_kernel does for the pixels whose ray misses the box around the scene, for those that miss the
+            // scene itself (a pixel that pass has marked already is left alone).
+            const unsigned pitem = (unsigned)P.item & kItemPixelMask;
+            const unsigned long long bit = 1ull << (pitem & 63u);
+            const unsigned long long old = atomicOr(&p.cull_mask_out[pitem >> 6], bit);
+            if ((old & bit) == 0ull) {
+                for (int b = 0; b < p.frame_blocks; ++b) p.blocksums[(size_t)pitem * p.frame_blocks + b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                atomicAdd(&p.counters[kCulledPixelsWord + kRaySlotStride * ((pitem >> 6) % kRaySlots)], 1ull);
+            }
+        }
         return kPixelDone;
     }
     const bool debug_shade = p.shade_mode == FF_SHADE_NORMAL_DEBUG;
@@ -1996,7 +2009,10 @@ __device__ __forceinline__ void init_path(Path& P)
 // shader drop out (together they cost the reference-like scenes 3.5 % otherwise, measured on one box).
 // BIG = 1 / 2 (with EXTRAS) are the instantiations for scenes of more than 32 geometries: candidates found by walking the tree
 // over the geometries (enter_top / geom_step) instead of scanning all records; 2: records read from global memory.
-template <bool STATS, int BLOCK, bool EXTRAS, int BIG = 0>
+// PREPASS = true is the instantiation that traces every pixel's primary ray once and stores its hit (settle_hit): the same loop on
+// one-ray items; a compile-time switch because its store / mask code inside the shading loop would cost the frame's own kernel
+// twenty spilled registers.
+template <bool STATS, int BLOCK, bool EXTRAS, int BIG = 0, bool PREPASS = false>
 __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
@@ -2031,7 +2047,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
     // stored by settle_hit) traces it ONCE per pixel; here every sample starts from the stored hit: no query, no traversal, no
     // resolution for the primary segment - one fifth of the headline frame's path segments.  (Rounds 3 kept the hit per lane and sample
     // block: one traced primary ray per 64 samples and 1.6 GB of parked hits written per 1080p frame.)
-    const bool reuse = p.primary_hits != nullptr && p.shade_mode != kShadePrimaryPass; // wave-uniform
+    const bool reuse = !PREPASS && p.primary_hits != nullptr; // wave-uniform
     // (the address is formed where it is used - a few instructions - rather than held in registers through the loop)
     auto stored_hit = [&](int k) { return p.primary_hits + (size_t)k * p.pix_items + ((unsigned)P.item & kItemPixelMask); };
     // instrumented launches only: wave cycles per phase (s_memtime), [0] resolve [1] shade [2] acquire [3] begin [4] traverse
@@ -2076,7 +2092,6 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             finish_segment(L, p.tris, P.ray, S, best);
             hit = best.geom >= 0;
         }
-        unsigned skipped = 0u;
         // A lane that waits with a new sample (it starts from the pixel's stored primary hit, see below) joins this iteration's shading.
         bool from_cache = setup && !inflight && active && P.b == 0 && reuse;
         if (STATS) t1 = __builtin_amdgcn_s_memtime();
@@ -2097,15 +2112,6 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 hit = best.geom >= 0;
                 cnt.rays += 1; // a path segment like any other, answered without a traversal (counted apart below)
                 settle_now = true;
-                if (!hit && P.item >= 0 && P.s < P.send - 1) {
-                    // Nothing in view: every sample of the block adds zero to its sum.  This sample becomes the block's last; the lane
-                    // books the path segments of the others (each a query answered with "nothing") itself - it is rare.
-                    const unsigned rest = (unsigned)(P.send - 1 - P.s);
-                    P.s = P.send - 1;
-                    cnt.rays += rest;
-                    skipped += rest;
-                    atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + tid / kWave) % kRaySlots)], (unsigned long long)rest);
-                }
             }
             {
                 const unsigned reused_now = (unsigned)__popcll(__ballot(from_cache));
@@ -2119,7 +2125,7 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
                 M.global = BIG == 2 ? p.geoms + (hit ? best.geom : 0) : nullptr;
                 M.geom_base = L.geom_base;
                 M.g = best.geom;
-                const int r = settle_hit<EXTRAS>(p, best, hit, M, P);
+                const int r = settle_hit<EXTRAS, PREPASS>(p, best, hit, M, P);
                 inflight = false;
                 active = r != kPixelDone;
                 goes_on = r == kGoesOn;
@@ -2128,7 +2134,6 @@ __global__ __launch_bounds__(BLOCK) void trace_bvh_kernel(const KParams p)
             settle_now = false;
             from_cache = waiting && __popcll(__ballot(waiting)) >= p.reuse_quorum;
         }
-        if (STATS && p.timeline) tl_count += (unsigned)wave_sum((unsigned long long)skipped); // (the timeline counts every path segment)
         if (goes_on) {
             MaterialRef M;
             M.global = BIG == 2 ? p.geoms + best.geom : nullptr;
@@ -2559,7 +2564,7 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
     bool more_meshes = false; // the lane's query has candidate meshes left (omeshes != 0)
     bool active = false, exhausted = false, inflight = false; // inflight: the lane has a query (begun, not yet shaded)
     bool waiting = false;                                     // ... and a job of it is out (queued, being walked, or handed back and not yet read)
-    const bool reuse = p.primary_hits != nullptr && p.shade_mode != kShadePrimaryPass; // every sample starts from its pixel's stored primary hit (trace_bvh_kernel)
+    const bool reuse = p.primary_hits != nullptr; // every sample starts from its pixel's stored primary hit (trace_bvh_kernel)
     unsigned long long tphase[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long wave_t0 = STATS ? wall_clock64() : 0ull;
     const int quorum = p.pool_quorum, qmin = p.pool_quorum_min;
@@ -2684,8 +2689,10 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
             bool settle_now = shade_now, goes_on = false;
             for (;;) {
                 if (from_cache) {
-                    const float4* stored = p.primary_hits + ((unsigned)P.item & kItemPixelMask);
-                    const float4 c0 = stored[0], c1 = stored[p.pix_items], c2 = stored[2 * (size_t)p.pix_items];
+                    const unsigned off = ((unsigned)P.item & kItemPixelMask) * 16u, plane = p.pix_items * 16u;
+                    const char* stored = reinterpret_cast<const char*>(p.primary_hits);
+                    const float4 c0 = *reinterpret_cast<const float4*>(stored + off), c1 = *reinterpret_cast<const float4*>(stored + (off + plane)),
+                                 c2 = *reinterpret_cast<const float4*>(stored + (off + 2u * plane));
                     best.dist = c0.x; best.px = c0.y; best.py = c0.z; best.pz = c0.w;
                     best.cx = c1.x; best.cy = c1.y; best.cz = c1.z;
                     best.geom = __float_as_int(c1.w);
@@ -2693,12 +2700,6 @@ __global__ __launch_bounds__(BLOCK) void trace_pool_kernel(const KParams p)
                     hit = best.geom >= 0;
                     cnt.rays += 1;
                     settle_now = true;
-                    if (!hit && P.item >= 0 && P.s < P.send - 1) { // nothing in view: the block ends with this sample (trace_bvh_kernel)
-                        const unsigned rest = (unsigned)(P.send - 1 - P.s);
-                        P.s = P.send - 1;
-                        cnt.rays += rest;
-                        atomicAdd(&p.counters[kAnsweredWord + kRaySlotStride * ((blockIdx.x * (BLOCK / kWave) + me / kWave) % kRaySlots)], (unsigned long long)rest);
-                    }
                 }
                 cnt.reused += (unsigned)__popcll(__ballot(from_cache));
                 if (__ballot(settle_now) == 0ull) break;
@@ -3155,6 +3156,15 @@ hipError_t prepare_kernels()
     FF_SET_LDS((trace_bvh_kernel<true, 768, true, 2>))
     FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 2>))
     FF_SET_LDS((trace_bvh_kernel<true, 1024, true, 2>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true, 0, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true, 0, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 0, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true, 1, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true, 1, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 1, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 512, true, 2, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 768, true, 2, true>))
+    FF_SET_LDS((trace_bvh_kernel<false, 1024, true, 2, true>))
     FF_SET_LDS((trace_pool_kernel<false, 1024, false>))
     FF_SET_LDS((trace_pool_kernel<false, 1024, true>))
     FF_SET_LDS((trace_pool_kernel<true, 1024, false>))
@@ -3169,10 +3179,28 @@ hipError_t prepare_kernels()
 size_t pool_lds_bytes(int block_threads) { return (size_t)block_threads * 48 + (size_t)kPoolRing * 2 + 128; } // jobs, ring, [head, tail, -, -], the role's inputs, the workgroup's tallies
 
 hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, int grid_blocks, int block_threads, hipStream_t stream,
-                        const char** kernel_name, bool pool)
+                        const char** kernel_name, bool pool, bool prepass)
 {
     const dim3 grid(grid_blocks);
     const char* name = "";
+    if (prepass) {
+        // the pre-pass of a frame (KParams::primary_hits): one instantiation per workgroup size and scene size, the general one
+        const dim3 block(block_threads);
+        const int big = p.num_geoms <= kChunkGeometries ? 0 : (p.num_geoms <= kMaxLdsRecords ? 1 : 2);
+        const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, big == 2 ? 0 : p.num_geoms);
+#define FF_LAUNCH_PRE(B)                                                                                                  \
+    do {                                                                                                                  \
+        if (big == 0) hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 0, true>), grid, block, lds, stream, p);      \
+        else if (big == 1) hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 1, true>), grid, block, lds, stream, p); \
+        else hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 2, true>), grid, block, lds, stream, p);               \
+    } while (0)
+        if (block_threads == 1024) FF_LAUNCH_PRE(1024);
+        else if (block_threads == 768) FF_LAUNCH_PRE(768);
+        else FF_LAUNCH_PRE(512);
+#undef FF_LAUNCH_PRE
+        if (kernel_name) *kernel_name = "trace_bvh_kernel<false, B, true, big, true>";
+        return hipGetLastError();
+    }
     if (trace_mode == FF_TRACE_BVH && pool && p.num_geoms <= kChunkGeometries && block_threads == 1024) {
         const dim3 block(block_threads);
         const size_t lds = bvh_lds_bytes(p.lds_nodes, p.stack_depth, block_threads, p.num_geoms) + pool_lds_bytes(block_threads);

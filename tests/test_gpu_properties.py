@@ -489,7 +489,7 @@ def test_culled_pixels_have_a_stored_primary_hit_for_their_tail_items():
     scene = scenes.cornell_wahoo_scene()
     w, h = 200, 150
     cam = scenes.posed_camera(w, h, position=(9.0, 4.0, 11.0), yaw=-130.0, pitch=-15.0)
-    for spp in (130, 512):
+    for spp in (192, 512):  # (three and eight blocks of 64: the last one is a full block, handed out in groups of 16 samples)
         with lib.Tracer(0) as t:
             t.upload_scene(scene)
             params = lib.render_params(w, h, 4, spp, 11)
