@@ -3198,7 +3198,7 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
         else if (block_threads == 768) FF_LAUNCH_PRE(768);
         else FF_LAUNCH_PRE(512);
 #undef FF_LAUNCH_PRE
-        if (kernel_name) *kernel_name = "trace_bvh_kernel<false, B, true, big, true>";
+        if (kernel_name) *kernel_name = "trace_bvh_kernel<false, B, true, big, true>"; // (the frame's own launches name their kernel exactly; nobody asks for this one)
         return hipGetLastError();
     }
     if (trace_mode == FF_TRACE_BVH && pool && p.num_geoms <= kChunkGeometries && block_threads == 1024) {
@@ -3225,17 +3225,17 @@ hipError_t launch_trace(const KParams& p, int trace_mode, bool collect_stats, in
 #define FF_LAUNCH_BVH(B)                                                                                                  \
     do {                                                                                                                  \
         if (big == 1) {                                                                                                   \
-            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, 1>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 1>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 1>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 1>"; } \
+            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, 1>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 1, false>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 1>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 1, false>"; } \
         } else if (big == 2) {                                                                                            \
-            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, 2>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 2>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 2>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 2>"; } \
+            if (collect_stats) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true, 2>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 2, false>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true, 2>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 2, false>"; } \
         } else if (collect_stats) {                                                                                       \
-            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 0>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false, 0>"; } \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<true, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", true, 0, false>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<true, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<true, " #B ", false, 0, false>"; } \
         } else {                                                                                                          \
-            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 0>"; } \
-            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false, 0>"; } \
+            if (spheres) { hipLaunchKernelGGL((trace_bvh_kernel<false, B, true>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", true, 0, false>"; } \
+            else { hipLaunchKernelGGL((trace_bvh_kernel<false, B, false>), grid, block, lds, stream, p); name = "trace_bvh_kernel<false, " #B ", false, 0, false>"; } \
         }                                                                                                                 \
     } while (0)
         if (block_threads == 1024) FF_LAUNCH_BVH(1024);

@@ -16,12 +16,12 @@ stats() {  # name, bench args...
 stats c2 --steps 3 --warmup 1
 tools/pmc_passes.sh "$OUT/pmc_c2" "sq1 sq2 sq3 sqc tcp tcc1 tcc2 grbm" --steps 1 --warmup 1 --no-companion
 python3 tools/pmc_summary.py "$OUT/pmc_c2" > "$OUT/${TAG}_c2_pmc_summary.txt"
-python3 tools/pmc_to_json.py "$OUT/pmc_c2" "$OUT/${TAG}_c2_pmc.json" "round 3 kernel (wall table with pairs, least-area 4-wide collapse, stack spill, primary-hit reuse, two-step shading, last-bounce cut)"
+python3 tools/pmc_to_json.py "$OUT/pmc_c2" "$OUT/${TAG}_c2_pmc.json" "round 4 kernel (round 3 + primary hits stored per pixel by a pre-pass, exact cull, as-asked tail zone of the work queue)"
 rm -rf "$OUT"/pmc_c2/*/
 stats c4 --scene c4 --steps 3 --warmup 1
 tools/pmc_passes.sh "$OUT/pmc_c4" "sq1 sq2 sq3 tcp tcc1 tcc2 grbm" --scene c4 --steps 1 --warmup 1 --no-companion
 python3 tools/pmc_summary.py "$OUT/pmc_c4" > "$OUT/${TAG}_c4_pmc_summary.txt"
-python3 tools/pmc_to_json.py "$OUT/pmc_c4" "$OUT/${TAG}_c4_pmc.json" "round 3 kernel, C4: the config whose tree does not fit LDS"
+python3 tools/pmc_to_json.py "$OUT/pmc_c4" "$OUT/${TAG}_c4_pmc.json" "round 4 kernel, C4: the config whose tree does not fit LDS"
 rm -rf "$OUT"/pmc_c4/*/
 cp "$OUT/${TAG}_c2_pmc.json" "$OUT/${TAG}_c4_pmc.json" profiles/  # (on the GPU box: so that the bench lines below find them)
 timeout -k 10 400 python3 bench.py --steps 5 --warmup 1 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
