@@ -50,10 +50,10 @@ def test_five_hundred_geometries_equal_brute_force_and_oracle(tracer):
     with lib.Tracer(0) as t:
         t.upload_scene(scene)
         t.render(cam, lib.render_params(32, 24, 1, 1))
-        assert t.kernel_name().endswith(", true, 2>")  # records in global memory, two-level traversal
+        assert t.kernel_name().endswith(", true, 2, false>")  # records in global memory, two-level traversal
         t.upload_scene(fz.rand_scene(np.random.default_rng(3), small=True, crowd=80))
         t.render(cam, lib.render_params(32, 24, 1, 1))
-        assert t.kernel_name().endswith(", true, 1>")  # records still in LDS
+        assert t.kernel_name().endswith(", true, 1, false>")  # records still in LDS
     small = scenes.posed_camera(28, 20, position=(0.5, 0.2, 4.5), yaw=-95.0, pitch=-4.0)
     p = lib.render_params(28, 20, 4, 2, 3, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH, T.GRID_FULL, 0)
     tracer.upload_scene(scene)
@@ -107,7 +107,7 @@ def test_big_scenes_with_walls_screened_first(tracer, walls, crowd):
     tracer.upload_scene(scene)
     bvh = tracer.render(cam, lib.render_params(w, h, 6, 3, 5))
     rays = tracer.stats().rays_traced
-    assert ", true, 1>" in tracer.kernel_name()
+    assert ", true, 1, false>" in tracer.kernel_name()
     brute = tracer.render(cam, lib.render_params(w, h, 6, 3, 5, trace_mode=T.TRACE_BRUTE_FORCE))
     assert rays == tracer.stats().rays_traced and bvh[1].any()
     assert np.array_equal(bvh[0], brute[0]) and np.array_equal(bvh[1].view(np.uint32), brute[1].view(np.uint32))

@@ -27,7 +27,7 @@ def isolated(a):
                 if "=" in kv:
                     k, v = kv.split("=", 1)
                     env[k] = v
-            cmd = [sys.executable, os.path.abspath(__file__), "--one", "--scene", a.scene, "--spp", str(a.spp), "--bounces", str(a.bounces), "--size", a.size, "--reps", "1", c]
+            cmd = [sys.executable, os.path.abspath(__file__), "--one", "--scene", a.scene, "--spp", str(a.spp), "--bounces", str(a.bounces), "--size", a.size, "--camera", a.camera, "--reps", "1", c]
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in out.stdout.splitlines() if l.startswith("ONE ")]
             if not line:
@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--camera", default="inside", choices=["inside", "default"], help="default: the reference's camera (kernel.cu:312-321), 12.5 units outside the box")
     ap.add_argument("--check", action="store_true", help="compare every configuration's radiance bits and ray count with the first one's")
     ap.add_argument("--isolate", action="store_true", help="one process per run: needed when a configuration names another library (FF_LIB_PATH=...)")
     ap.add_argument("--one", action="store_true", help=argparse.SUPPRESS)
@@ -62,6 +63,8 @@ def main():
     w, h = (int(v) for v in a.size.split("x"))
     scene = {"c2": scenes.cornell_wahoo_scene, "c3": scenes.blooper_scene, "c4": scenes.sphere_stress_scene}[a.scene]()
     cam = scenes.posed_camera(w, h, position=(4.0, 1.0, 7.0), yaw=-118.0, pitch=-8.0) if a.scene == "c3" else scenes.posed_camera(w, h, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    if a.camera == "default":
+        cam = scenes.default_camera(w, h)
     params = lib.render_params(w, h, a.bounces, a.spp, 1234)
     if a.one:
         import json
