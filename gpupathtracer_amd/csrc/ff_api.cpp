@@ -155,7 +155,7 @@ int finalize_layout(FfState* s)
         FF_HIP(hipStreamSynchronize(s->stream)); // (`top4` goes out of scope)
     }
     // the axis-aligned walls among the planes every query screens (all planes of a small scene, the leading num_scan of a big one)
-    build_wall_table(s->h_geoms.data(), s->sw.no_wall_table ? 0 : (s->num_geoms > kChunkGeometries ? s->num_scan : s->num_quads), s->walls, !s->sw.no_wall_pairs, !s->sw.no_room);
+    build_wall_table(s->h_geoms.data(), s->sw.no_wall_table ? 0 : (s->num_geoms > kChunkGeometries ? s->num_scan : s->num_quads), s->walls, !s->sw.no_wall_pairs);
     if (s->num_geoms <= kChunkGeometries) add_mesh_boxes(s->h_geoms.data(), s->num_planes, s->num_geoms, s->walls);
     // one entry per visited node above the cursor (inner_step) plus a spare; in big scenes the pending entries of the
     // geometry tree sit below a mesh's own
@@ -678,7 +678,6 @@ void read_switches(FfState* s)
     if (const char* e = std::getenv("FF_QUEUE_COUNTERS")) w.queue_counters = std::max(1, std::min(kQueueCounters, std::atoi(e)));
     w.no_wall_table = std::getenv("FF_NO_WALL_TABLE") != nullptr;
     w.no_wall_pairs = std::getenv("FF_NO_WALL_PAIRS") != nullptr;
-    w.no_room = std::getenv("FF_NO_ROOM") != nullptr;
     w.no_stack_spill = std::getenv("FF_NO_STACK_SPILL") != nullptr;
     w.no_scan_planes = std::getenv("FF_NO_SCAN_PLANES") != nullptr;
     if (const char* e = std::getenv("FF_DEBUG_LDS_FILL")) w.lds_fill = std::sscanf(e, "%lu,%lx", &w.lds_fill_words, &w.lds_fill_pattern) == 2;

@@ -124,22 +124,13 @@ struct WallTable {
         float mx[3];
         int pad;
     } box[32];
-    // Walls that are the faces of ONE axis-aligned box (a room: build_wall_table finds it; faces == 0: none).  A ray that starts
-    // inside the box leaves it through exactly one face: one slab exit instead of one test per wall (screen_walls).  The walls are
-    // entries of the table all the same (origins outside the box, and on its faces, take the general route); `entries` marks them.
-    struct Room {
-        float lo[3], hi[3];         // the box
-        int geom_lo[3], geom_hi[3]; // record of the wall on each face, -1: the face is open
-        unsigned entries;           // bit i: entry w[i] holds room walls only
-        int faces;                  // walls that are faces of the box
-    } room;
 };
 
 // Fills the table from the plane records [0, limit) (processing order; limit <= 32).  A plane qualifies when the three axis
 // columns of its model matrix are parallel to three different world axes to within 2e-7 of their lengths (rotations by multiples
 // of 90 degrees come out of glm's cos/sin that exact), its normal is the unit quad's (0, 0, 1) and its scales differ by at most a
 // factor of 16.  At most kMaxWalls planes, the leading (largest) ones.
-void build_wall_table(const struct GeomRecord* geoms, int limit, WallTable& out, bool pairing = true, bool room = true); // pairing: walls that share a rectangle share an entry; room: look for walls that are faces of one box
+void build_wall_table(const struct GeomRecord* geoms, int limit, WallTable& out, bool pairing = true); // pairing: walls that share a rectangle share an entry
 // ... and the mesh boxes of a small scene (records [first, n), n <= 32).
 void add_mesh_boxes(const struct GeomRecord* geoms, int first, int n, WallTable& out);
 

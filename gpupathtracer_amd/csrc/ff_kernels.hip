@@ -714,14 +714,13 @@ __device__ __forceinline__ void screen_analytic(const LDS& L, int g, const TriRe
 // error of the parameter moves the point by that times d_u / d_k) - and by more than `tt` in the parameter's sign.  NaNs (an
 // origin beyond 1e8) compare false everywhere and land in `slow`.
 __device__ __forceinline__ void wall_test(const Wall& w, float ixk, float oxk, float ou, float du, float ov, float dv, float dl, float tt, bool steep,
-                                          float wlen, float& best_d, int& best_g, bool& tie, unsigned& slow, bool skip = false)
+                                          float wlen, float& best_d, int& best_g, bool& tie, unsigned& slow)
 {
-    // (skip: the lane has dealt with this wall already - a room wall, room_exit - and it counts as a certain miss here)
     const float t = __builtin_fmaf(w.c, ixk, oxk);
     const float pu = __builtin_fmaf(t, du, ou), pv = __builtin_fmaf(t, dv, ov);
     const float m = fmaxf(fabsf(pu - w.cu) - w.hu, fabsf(pv - w.cv) - w.hv); // > 0: outside the rectangle by that much
-    const bool hit = m <= -dl && t > tt && steep && !skip;
-    const bool miss = m > dl || t < -tt || skip;
+    const bool hit = m <= -dl && t > tt && steep;
+    const bool miss = m > dl || t < -tt;
     // Straight-line selects throughout.  (The two rare cases - a lane inside a margin, a second certain hit that is not clearly
     // nearer - behind wave-uniform branches instead: C2 -3 %, the default camera -4 %.  A branch costs this loop more than the
     // five vector instructions it skips.)
@@ -740,17 +739,17 @@ __device__ __forceinline__ void wall_test(const Wall& w, float ixk, float oxk, f
 // the other wall is a certain miss when its own parameter is certainly negative (the same criterion as above) and goes to the
 // per-lane screen otherwise (an origin outside the pair, or on the wall itself).
 __device__ __forceinline__ void wall_test_pair(const Wall& w, float ixk, float oxk, float ou, float du, float ov, float dv, float dl, float tt, bool steep,
-                                               float wlen, float& best_d, int& best_g, bool& tie, unsigned& slow, bool skip = false)
+                                               float wlen, float& best_d, int& best_g, bool& tie, unsigned& slow)
 {
     const float tlo = __builtin_fmaf(w.c, ixk, oxk), thi = __builtin_fmaf(w.hi_c, ixk, oxk);
     const bool up = ixk > 0.0f;
     const float t = up ? thi : tlo, tother = up ? tlo : thi;
     const int g = up ? w.hi_geom1 - 1 : w.geom, gother = up ? w.geom : w.hi_geom1 - 1;
-    slow |= !(tother < -tt) && !skip ? 1u << gother : 0u;
+    slow |= !(tother < -tt) ? 1u << gother : 0u;
     const float pu = __builtin_fmaf(t, du, ou), pv = __builtin_fmaf(t, dv, ov);
     const float m = fmaxf(fabsf(pu - w.cu) - w.hu, fabsf(pv - w.cv) - w.hv);
-    const bool hit = m <= -dl && t > tt && steep && !skip;
-    const bool miss = m > dl || t < -tt || skip;
+    const bool hit = m <= -dl && t > tt && steep;
+    const bool miss = m > dl || t < -tt;
     slow |= (!hit && !miss) ? 1u << g : 0u;
     const float d = t * wlen;
     const bool nearer = hit && best_d > __builtin_fmaf(d, 1.0f + kRel, kAbs);
@@ -758,42 +757,6 @@ __device__ __forceinline__ void wall_test_pair(const Wall& w, float ixk, float o
     tie = tie || (hit && !nearer && !farther);
     best_d = nearer ? d : best_d;
     best_g = nearer ? g : best_g;
-}
-
-// The room (WallTable::Room: walls that are the faces of one axis-aligned box) against a ray that starts INSIDE the box: the ray leaves
-// the box through exactly one face - the nearest of the three its direction points at - so one slab exit replaces a test per wall.
-// Same three outcomes as wall_test, with the same margins: a certain hit (the exit point lies inside the face's rectangle by more
-// than dl, the axis is steep, and the parameter is positive by construction: the origin is inside by more than the margin `th`
-// below which a wall's side is not certain), certainly nothing (the face is open, say the front of a Cornell box), or the three
-// walls the direction points at go to the per-lane screens, which decide with the exact reference test (an exit next to an edge).
-// The walls behind the origin are certain misses for the same reason the parameter is positive.  Returns false for an origin
-// that is not inside (outside, on a face, NaN): the room's walls are then screened one by one like any others.
-__device__ __forceinline__ bool room_exit(const WallTable::Room& R, const Ray& wr, const WorldSlab& ws, float D, float th, float gmin, float wlen, float& best_d,
-                                          int& best_g, unsigned& slow)
-{
-    const bool inside = wr.ox - R.lo[0] > th && R.hi[0] - wr.ox > th && wr.oy - R.lo[1] > th && R.hi[1] - wr.oy > th && wr.oz - R.lo[2] > th && R.hi[2] - wr.oz > th;
-    const bool px = ws.ix > 0.0f, py = ws.iy > 0.0f, pz = ws.iz > 0.0f;
-    const float tx = __builtin_fmaf(px ? R.hi[0] : R.lo[0], ws.ix, ws.ox), ty = __builtin_fmaf(py ? R.hi[1] : R.lo[1], ws.iy, ws.oy),
-                tz = __builtin_fmaf(pz ? R.hi[2] : R.lo[2], ws.iz, ws.oz);
-    const int gx = px ? R.geom_hi[0] : R.geom_lo[0], gy = py ? R.geom_hi[1] : R.geom_lo[1], gz = pz ? R.geom_hi[2] : R.geom_lo[2];
-    const float t = fminf(fminf(tx, ty), tz);
-    const bool kx = tx <= ty && tx <= tz, ky = !kx && ty <= tz;
-    const int g = kx ? gx : (ky ? gy : gz);
-    // how far inside the box the exit point lies along each axis; along the exit axis itself it is on the face, and does not count
-    const float qx = __builtin_fmaf(t, wr.dx, wr.ox), qy = __builtin_fmaf(t, wr.dy, wr.oy), qz = __builtin_fmaf(t, wr.dz, wr.oz);
-    const float mx = fminf(qx - R.lo[0], R.hi[0] - qx), my = fminf(qy - R.lo[1], R.hi[1] - qy), mz = fminf(qz - R.lo[2], R.hi[2] - qz);
-    const float m = kx ? fminf(my, mz) : (ky ? fminf(mz, mx) : fminf(mx, my));
-    const float ax = fabsf(wr.dx), ay = fabsf(wr.dy), az = fabsf(wr.dz);
-    const float ak = kx ? ax : (ky ? ay : az), aother = kx ? fmaxf(ay, az) : (ky ? fmaxf(az, ax) : fmaxf(ax, ay));
-    const float aik = fabsf(kx ? ws.ix : (ky ? ws.iy : ws.iz));
-    const float dl = D * __builtin_fmaf(aother, aik, 1.0f);
-    const bool sure = m > dl && ak >= gmin; // (a NaN compares false: not sure)
-    if (inside && sure && g >= 0) {
-        best_d = t * wlen;
-        best_g = g;
-    }
-    if (inside && !sure) slow |= (gx >= 0 ? 1u << gx : 0u) | (gy >= 0 ? 1u << gy : 0u) | (gz >= 0 ? 1u << gz : 0u);
-    return inside;
 }
 
 // All walls of the table against the calling lanes' rays (wave-uniform loops; the table comes through scalar loads).  Must run
@@ -813,13 +776,6 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
     float best_d = kInf;
     int best_g = -1;
     bool tie = false;
-    // the room first: lanes that start inside it are through with its walls; if all calling lanes are, its entries are skipped
-    bool roomed = false;
-    unsigned skip_entries = 0u;
-    if (W.room.faces != 0) {
-        roomed = room_exit(W.room, wr, ws, D, th, gmin, wlen, best_d, best_g, slow);
-        if (__ballot(!roomed) == 0ull) skip_entries = W.room.entries;
-    }
     // (the record of the next wall is requested before the current one is tested: a scalar load per iteration would otherwise
     // sit in front of every test)
     Wall cur = W.w[0];
@@ -829,11 +785,8 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
         const bool steep = ax >= gmin;
         for (; i < nx; ++i) {
             const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
-            if (((skip_entries >> i) & 1u) == 0u) {
-                const bool skip = roomed && ((W.room.entries >> i) & 1u) != 0u;
-                if (cur.hi_geom1) wall_test_pair(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow, skip);
-                else wall_test(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow, skip);
-            }
+            if (cur.hi_geom1) wall_test_pair(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            else wall_test(cur, ws.ix, ws.ox, wr.oy, wr.dy, wr.oz, wr.dz, dl, tt, steep, wlen, best_d, best_g, tie, slow);
             cur = nxt;
         }
     }
@@ -842,11 +795,8 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
         const bool steep = ay >= gmin;
         for (; i < ny; ++i) {
             const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
-            if (((skip_entries >> i) & 1u) == 0u) {
-                const bool skip = roomed && ((W.room.entries >> i) & 1u) != 0u;
-                if (cur.hi_geom1) wall_test_pair(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow, skip);
-                else wall_test(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow, skip);
-            }
+            if (cur.hi_geom1) wall_test_pair(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            else wall_test(cur, ws.iy, ws.oy, wr.oz, wr.dz, wr.ox, wr.dx, dl, tt, steep, wlen, best_d, best_g, tie, slow);
             cur = nxt;
         }
     }
@@ -855,11 +805,8 @@ __device__ __forceinline__ void screen_walls(const WallTable& W, const Ray& wr, 
         const bool steep = az >= gmin;
         for (; i < nz; ++i) {
             const Wall nxt = W.w[min(i + 1, kMaxWalls - 1)];
-            if (((skip_entries >> i) & 1u) == 0u) {
-                const bool skip = roomed && ((W.room.entries >> i) & 1u) != 0u;
-                if (cur.hi_geom1) wall_test_pair(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow, skip);
-                else wall_test(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow, skip);
-            }
+            if (cur.hi_geom1) wall_test_pair(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow);
+            else wall_test(cur, ws.iz, ws.oz, wr.ox, wr.dx, wr.oy, wr.dy, dl, tt, steep, wlen, best_d, best_g, tie, slow);
             cur = nxt;
         }
     }

@@ -502,7 +502,7 @@ int count_scan_planes(const std::vector<GeomRecord>& geoms, int num_quads)
     return n;
 }
 
-void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out, bool pairing, bool room)
+void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out, bool pairing)
 {
     std::memset(&out, 0, sizeof out);
     struct Found {
@@ -551,51 +551,6 @@ void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out, bool p
     // Two walls normal to the same axis with the same rectangle (floor and ceiling, left and right wall of a box) share one entry:
     // a ray between them can reach only the one its direction points at, so the kernel computes both parameters, tests the
     // rectangle once and hands the other wall to the per-lane screens unless its parameter is certainly negative (wall_test_pair).
-    // The walls that are faces of one axis-aligned box (a room).  Seeded by any wall: its rectangle gives the box's extent along its
-    // two in-plane axes, the rectangle of a wall normal to one of those gives the extent along the third; a wall is a face when its
-    // plane is one end of the box along its normal and its rectangle is the box's cross-section there (to 1e-6 of the scene's scale:
-    // three orders below the screening margins, which is what makes "is" good enough).  Three faces at least.
-    std::vector<char> in_room(found.size(), 0);
-    if (room) {
-        const float eps = 1.0e-6f * std::max(scale_s, 1e-20f);
-        auto near_eq = [&](float a, float b) { return std::fabs(a - b) <= eps; };
-        auto extent = [&](const Found& f, int axis, float& a, float& b) { // the wall's rectangle along world axis `axis` (one of its in-plane axes)
-            const int u = (f.axis + 1) % 3;
-            if (axis == u) { a = f.w.cu - f.w.hu; b = f.w.cu + f.w.hu; }
-            else { a = f.w.cv - f.w.hv; b = f.w.cv + f.w.hv; }
-        };
-        for (size_t seed = 0; seed < found.size() && out.room.faces == 0; ++seed) {
-            const int k = found[seed].axis, u = (k + 1) % 3, v = (k + 2) % 3;
-            float lo[3], hi[3];
-            extent(found[seed], u, lo[u], hi[u]);
-            extent(found[seed], v, lo[v], hi[v]);
-            bool have_k = false;
-            for (size_t j = 0; j < found.size() && !have_k; ++j) {
-                if (found[j].axis == k) continue;
-                extent(found[j], k, lo[k], hi[k]);
-                have_k = near_eq(found[seed].w.c, lo[k]) || near_eq(found[seed].w.c, hi[k]);
-            }
-            if (!have_k || !(lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2])) continue;
-            WallTable::Room R;
-            std::memset(&R, 0, sizeof R);
-            for (int a = 0; a < 3; ++a) { R.lo[a] = lo[a]; R.hi[a] = hi[a]; R.geom_lo[a] = R.geom_hi[a] = -1; }
-            std::vector<char> face(found.size(), 0);
-            for (size_t j = 0; j < found.size(); ++j) {
-                const Found& f = found[j];
-                const int a = f.axis, fu = (a + 1) % 3, fv = (a + 2) % 3;
-                float u0, u1, v0, v1;
-                extent(f, fu, u0, u1);
-                extent(f, fv, v0, v1);
-                if (!(near_eq(u0, lo[fu]) && near_eq(u1, hi[fu]) && near_eq(v0, lo[fv]) && near_eq(v1, hi[fv]))) continue;
-                if (near_eq(f.w.c, lo[a]) && R.geom_lo[a] < 0) { R.geom_lo[a] = f.w.geom; face[j] = 1; ++R.faces; }
-                else if (near_eq(f.w.c, hi[a]) && R.geom_hi[a] < 0) { R.geom_hi[a] = f.w.geom; face[j] = 1; ++R.faces; }
-            }
-            if (R.faces >= 3) {
-                out.room = R;
-                in_room = face;
-            }
-        }
-    }
     std::vector<char> used(found.size(), 0);
     int n = 0;
     for (int axis = 0; axis < 3; ++axis)
@@ -603,14 +558,12 @@ void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out, bool p
             if (found[i].axis != axis || used[i]) continue;
             used[i] = 1;
             Wall w = found[i].w;
-            bool all_room = in_room[i] != 0;
             out.mask |= 1u << w.geom;
             for (size_t j = i + 1; pairing && j < found.size(); ++j) {
                 const Wall& o = found[j].w;
                 if (found[j].axis != axis || used[j] || o.c == w.c) continue;
                 if (std::memcmp(&o.cu, &w.cu, 4 * sizeof(float)) != 0) continue; // cu, hu, cv, hv bit for bit
                 used[j] = 1;
-                all_room = all_room && in_room[j] != 0;
                 out.mask |= 1u << o.geom;
                 const Wall& lo = o.c < w.c ? o : w;
                 const Wall& hi = o.c < w.c ? w : o;
@@ -620,11 +573,9 @@ void build_wall_table(const GeomRecord* geoms, int limit, WallTable& out, bool p
                 w = both;
                 break;
             }
-            if (all_room) out.room.entries |= 1u << n;
             out.w[n++] = w;
             out.count[axis] += 1;
         }
-    if (out.room.entries == 0u) out.room.faces = 0; // (a room none of whose walls has an entry of its own buys nothing)
     // margins: both scale with the anisotropy of the walls (a rounding error of the object-space test along a short axis is that
     // much larger in world units along a long one)
     out.margin_s = ratio * scale_s;
@@ -945,7 +896,7 @@ extern "C" int ff_debug_wall_table(const FfGeometry* host_geometries, int n, flo
     int num_quads = 0;
     for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
     WallTable t;
-    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr, std::getenv("FF_NO_ROOM") == nullptr); // (stateless test helper: the environment decides)
+    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr); // (stateless test helper: the environment decides)
     int count = 0, i = 0;
     for (int axis = 0; axis < 3; ++axis)
         for (int k = 0; k < t.count[axis]; ++k, ++i) {
@@ -963,20 +914,6 @@ extern "C" int ff_debug_wall_table(const FfGeometry* host_geometries, int n, flo
     return count;
 }
 
-extern "C" int ff_debug_room_faces(const FfGeometry* host_geometries, int n)
-{
-    using namespace ff;
-    clear_error();
-    CompiledScene cs;
-    const int st = compile_scene(host_geometries, n, default_bvh_params(), cs, /*build_bvh=*/false);
-    if (st != FF_OK) return -st;
-    int num_quads = 0;
-    for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
-    WallTable t;
-    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr, std::getenv("FF_NO_ROOM") == nullptr);
-    return t.room.faces;
-}
-
 extern "C" int ff_debug_wall_entries(const FfGeometry* host_geometries, int n)
 {
     using namespace ff;
@@ -987,6 +924,6 @@ extern "C" int ff_debug_wall_entries(const FfGeometry* host_geometries, int n)
     int num_quads = 0;
     for (const GeomRecord& g : cs.geoms) num_quads += g.type == FF_GEOM_PLANE ? 1 : 0;
     WallTable t;
-    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr, std::getenv("FF_NO_ROOM") == nullptr); // (stateless test helper: the environment decides)
+    build_wall_table(cs.geoms.data(), num_quads, t, std::getenv("FF_NO_WALL_PAIRS") == nullptr); // (stateless test helper: the environment decides)
     return t.count[0] + t.count[1] + t.count[2];
 }

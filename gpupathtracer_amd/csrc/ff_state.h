@@ -99,7 +99,6 @@ struct FfState {
         int reuse_quorum = 1;
         int queue_chunk = 0, queue_counters = 0; // 0: the library's choice
         int queue_tail = -1;           // FF_QUEUE_TAIL: items per wave in the as-asked tail zone of the work queue (-1: the library's choice, 0: off)
-        bool no_room = false;          // FF_NO_ROOM: walls that are faces of one box are screened one by one like any others
         bool no_wall_table = false, no_wall_pairs = false, no_stack_spill = false, no_scan_planes = false; // layout (finalize_layout / scene compile)
         bool lds_fill = false;         // FF_DEBUG_LDS_FILL=words,pattern
         unsigned long lds_fill_words = 0, lds_fill_pattern = 0;

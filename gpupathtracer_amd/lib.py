@@ -18,7 +18,7 @@ EXPORTS = [
     "ff_create", "ff_destroy", "ff_last_error", "ff_version", "ff_set_stream",
     "ff_geometry_init", "ff_bxdf_init", "ff_camera_init_default", "ff_camera_update_basis", "ff_camera_ray_matrix",
     "ff_render_tile", "ff_upload_scene", "ff_set_builder", "ff_update_transforms", "ff_update_mesh", "ff_build_stats", "ff_debug_download_bvh", "ff_debug_download_bvh4",
-    "ff_scene_info", "ff_debug_wall_table", "ff_debug_wall_entries", "ff_debug_room_faces", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
+    "ff_scene_info", "ff_debug_wall_table", "ff_debug_wall_entries", "ff_render", "ff_render_strips", "ff_strips_local_rows", "ff_deinterleave_strips",
     "ff_intersect_rays", "ff_register_gl_pbo", "ff_unregister_gl_pbo", "ff_render_to_pbo",
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
     "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_timeline", "ff_debug_check_ieee", "ff_debug_reload_switches", "ff_load_obj", "ff_free_triangles",

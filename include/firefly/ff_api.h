@@ -139,9 +139,6 @@ FF_API int ff_debug_wall_table(const FfGeometry* host_geometries, int n, float* 
 /* ... and the number of ENTRIES of that table: two walls normal to the same axis with the same rectangle (floor and ceiling of a box)
  * share one, so this is at most the count above.  Needs no GPU. */
 FF_API int ff_debug_wall_entries(const FfGeometry* host_geometries, int n);
-/* ... and how many of those walls are the faces of ONE axis-aligned box (a room: rays that start inside it find the wall they leave
- * through with one slab exit instead of one test per wall; csrc/ff_kernels.hip room_exit); 0: no such box (or FF_NO_ROOM is set). */
-FF_API int ff_debug_room_faces(const FfGeometry* host_geometries, int n);
 
 /* ---- rendering (kernel.cu:335-344 + launchPathTrace kernel.cu:218-221) -------------------------- */
 

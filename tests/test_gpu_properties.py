@@ -596,9 +596,8 @@ def test_last_bounce_queries_end_after_the_planes_when_no_emitter_is_held(tracer
 
 def test_wall_pairs_and_wall_table_do_not_change_a_bit(monkeypatch):
     """Floor and ceiling, left and right wall of the box share one entry of the wall table (csrc/ff_scene.cpp build_wall_table,
-    csrc/ff_kernels.hip wall_test_pair), and together with the back wall they are the faces of one box that rays from inside leave
-    through one slab exit (room_exit): with pairs, without them (FF_NO_WALL_PAIRS=1), without the room (FF_NO_ROOM=1) and without the
-    table (FF_NO_WALL_TABLE=1; all read at ff_create) the frame is the same, from inside the box, from outside it (origins beyond the pair: the other wall
+    csrc/ff_kernels.hip wall_test_pair): with pairs, without them (FF_NO_WALL_PAIRS=1) and without the table (FF_NO_WALL_TABLE=1;
+    both read at ff_create) the frame is the same, from inside the box, from outside it (origins beyond the pair: the other wall
     goes to the exact per-lane screen) and from a camera ON the floor plane."""
     scene = scenes.cornell_wahoo_scene()
     cams = [scenes.posed_camera(80, 48, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0),
@@ -607,7 +606,7 @@ def test_wall_pairs_and_wall_table_do_not_change_a_bit(monkeypatch):
             scenes.posed_camera(80, 48, position=(0.5, -2.5, 2.0), yaw=-95.0, pitch=10.0)]    # on the floor's plane
     params = lib.render_params(80, 48, 5, 6, 9)
     frames = {}
-    for knob in (None, "FF_NO_WALL_PAIRS", "FF_NO_WALL_TABLE", "FF_NO_ROOM"):
+    for knob in (None, "FF_NO_WALL_PAIRS", "FF_NO_WALL_TABLE"):
         if knob:
             monkeypatch.setenv(knob, "1")
         with lib.Tracer(0) as t:
@@ -615,7 +614,7 @@ def test_wall_pairs_and_wall_table_do_not_change_a_bit(monkeypatch):
             frames[knob] = [t.render(cam, params)[1].copy() for cam in cams]
         if knob:
             monkeypatch.delenv(knob)
-    for knob in ("FF_NO_WALL_PAIRS", "FF_NO_WALL_TABLE", "FF_NO_ROOM"):
+    for knob in ("FF_NO_WALL_PAIRS", "FF_NO_WALL_TABLE"):
         for a, b in zip(frames[None], frames[knob]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), knob
     assert frames[None][0].max() > 0

@@ -233,28 +233,6 @@ def test_wall_table_takes_axis_aligned_planes_only(ff):
         assert np.array_equal(table(box), w_box)
     finally:
         del os.environ["FF_NO_WALL_PAIRS"]
-    # Left, right, floor, ceiling and back wall are faces of ONE box (the front is open; the light is a rectangle of its own under the
-    # ceiling): a room of five faces, which rays that start inside leave through one slab exit (csrc/ff_kernels.hip room_exit).
-    lib.ff_debug_room_faces.argtypes = [C.POINTER(T.FfGeometry), C.c_int]
-    assert lib.ff_debug_room_faces(box.geometries, len(box)) == 5
-    os.environ["FF_NO_ROOM"] = "1"
-    try:
-        assert lib.ff_debug_room_faces(box.geometries, len(box)) == 0
-    finally:
-        del os.environ["FF_NO_ROOM"]
-    assert lib.ff_debug_room_faces(s.geometries, len(s)) == 0  # one lone wall: no room
-    two = scenes.Scene()
-    two.add_plane((0, -2.5, 0), (90, 0, 0), (5, 5, 5), grey)   # a floor and a ceiling alone span no box along x and z
-    two.add_plane((0, 2.5, 0), (90, 0, 0), (5, 5, 5), grey)
-    two.add_sphere(1.0, (0, 0, 0), (0, 0, 0), (1, 1, 1), grey)
-    assert lib.ff_debug_room_faces(two.finalize().geometries, 3) == 0
-    shifted = scenes.Scene()                                       # floor + back + left of a 4 x 2 x 6 box, and a right wall that is too low to be its face
-    shifted.add_plane((0, -1, 0), (90, 0, 0), (4, 6, 1), grey)
-    shifted.add_plane((0, 0, -3), (0, 0, 0), (4, 2, 1), grey)
-    shifted.add_plane((-2, 0, 0), (0, 90, 0), (6, 2, 1), grey)
-    shifted.add_plane((2, -0.5, 0), (0, 90, 0), (6, 1, 1), grey)
-    shifted.add_sphere(0.5, (0, 0, 0), (0, 0, 0), (1, 1, 1), grey)
-    assert lib.ff_debug_room_faces(shifted.finalize().geometries, 5) == 3
 
 
 def test_builder_arrivals_wait_for_their_stores():
