@@ -9,7 +9,7 @@ echo "== evidence"; tools/evidence_run.sh $OUT $TAG 2>&1 | grep -v "^{" | tail -
 echo "== same-box A/B against the round's earlier builds"
 L0=FF_LIB_PATH=$PWD/build_var/r3/lib_zz_final.so; L1=FF_LIB_PATH=$PWD/build_var/r4/libff_e62f4da_before_prepass.so; L2=FF_LIB_PATH=$PWD/build_var/r4/libff_b_prepass_template.so
 for spec in "c2 1024" "c2 256" "c4 128" "c3 512" "c2 16" "c2 1"; do set -- $spec
-  timeout -k 5 600 python tools/pool_sweep.py --isolate --scene $1 --spp $2 --reps 3 "$L0" "$L1" "$L2" "FF_DUMMY=1" "FF_NO_ROOM=1" 2>&1 | grep -v "^  rep" | sed "s#$PWD/##" | cut -c1-200 | tee -a $OUT/${TAG}_ab_builds.txt
+  timeout -k 5 600 python tools/pool_sweep.py --isolate --scene $1 --spp $2 --reps 3 "$L0" "$L1" "$L2" "FF_DUMMY=1" 2>&1 | grep -v "^  rep" | sed "s#$PWD/##" | cut -c1-200 | tee -a $OUT/${TAG}_ab_builds.txt
 done
 echo "== occupancy probe"; timeout -k 5 200 python tools/occupancy_probe.py 64 c2 > $OUT/${TAG}_occupancy_c2.txt 2>&1; tail -12 $OUT/${TAG}_occupancy_c2.txt
 echo "== strips"; timeout -k 5 300 python tools/strip_scaling.py 1024 > $OUT/${TAG}_strip_scaling.txt 2>&1; cat $OUT/${TAG}_strip_scaling.txt
