@@ -566,7 +566,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         // rays are not path segments of the frame: the kernel does not count them, and the work queue starts from zero again behind it.  (Always the lane-
         // owned kernel, never instrumented: the frame's own launches are what the statistics describe.)
         KParams kp = k;
-        kp.shade_mode = 100; // kShadePrimaryPass (ff_kernels.hip)
+        kp.shade_mode = kShadePrimaryPass;
         kp.primary_hits = s->d_primary_cache;
         kp.bounces = 1;
         kp.spp_total = 1;

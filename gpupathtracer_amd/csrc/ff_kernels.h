@@ -124,6 +124,7 @@ constexpr int kTimelineBuckets = 1024;
 constexpr int kQueueCounters = 64;     // buffer size; a launch uses kQueueCountersDefault of them unless FF_QUEUE_COUNTERS says otherwise
 constexpr int kQueueCountersDefault = 16;
 constexpr int kQueueStride = 1024; // in 4-byte words
+constexpr int kShadePrimaryPass = 100; // KParams::shade_mode of a frame's pre-pass (beyond FfShadeMode's values): every pixel's primary ray, its hit stored (settle_hit)
 constexpr int kQueueStripe = 64;   // items: counter c owns the stripes c, c + n, c + 2n, ... of the item range
 constexpr int kQueueTailWord = 64; // the counter of a share's last items sits this many words behind its chunk counter (another 256-byte line of the same 4 KiB)
 

@@ -310,7 +310,6 @@ constexpr int kPackedEntry = 0x40000000;                  // stack entry that na
 constexpr unsigned kItemPixelMask = 0x1FFFFFFu;           // Path::item: the pixel item number (the host keeps pix_items below 2^25) ...
 constexpr int kItemBlockShift = 25;                       // ... the sample block above it (at most 16 blocks per pixel) ...
 constexpr unsigned kItemTail = 0x80000000u;               // ... and the sign bit for tail items
-constexpr int kShadePrimaryPass = 100;                    // KParams::shade_mode of the pre-pass that traces every pixel's primary ray once (settle_hit)
 
 struct LdsBase {
     int node_cap;   // LDS node slots: quarter k of LDS node j lives at uint4 index k * node_cap + j

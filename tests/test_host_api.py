@@ -249,3 +249,30 @@ def test_builder_arrivals_wait_for_their_stores():
     out = subprocess.run([_sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 violations" in out.stdout and " 0 arrival atomics" not in out.stdout
+
+
+def test_bench_reuses_the_one_gpu_counter_file_for_more_ranks():
+    """with N > 1 ranks there is no N-GPU counter file (the pool's boxes have one GPU); a rank runs the same
+    kernel instantiation on a strip subset of the same frame, so bench.py applies the N = 1 file's per-segment figures when kernel
+    name and source hash match, and says so (`pmc_scope: "n1"`).  A file from other sources is refused for every N."""
+    import argparse
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ff_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from gpupathtracer_amd.provenance import kernel_source_hash
+    files = [f for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if f.endswith("_c2_pmc.json")]
+    assert files
+    newest = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+    w = newest["workload"]
+    args = argparse.Namespace(width=w["width"], height=w["height"], bounces=w["bounces"], spp=w["spp"], camera=w["camera"], trace_mode=w["trace"], scene=w.get("scene", "c2"))
+    one, why1, scope1 = bench.measured_pmc(args, 1, newest["kernel"])
+    many, why8, scope8 = bench.measured_pmc(args, 8, newest["kernel"])
+    if newest.get("kernel_source_hash") == kernel_source_hash():
+        assert one is not None and scope1 == "exact" and many is not None and scope8 == "n1"
+        assert many["valu_insts_per_ray"] == one["valu_insts_per_ray"] and many["file"] == one["file"]
+    else:  # the tree has moved on since the counters were taken: withheld for every N, with the reason
+        assert one is None and many is None and "other kernel sources" in why1 and scope8 is None
+    other, why, _ = bench.measured_pmc(args, 8, "trace_bvh_kernel<false, 512, false, 0, false>")
+    assert other is None and why

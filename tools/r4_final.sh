@@ -15,6 +15,6 @@ echo "== occupancy probe"; timeout -k 5 200 python tools/occupancy_probe.py 64 c
 echo "== strips"; timeout -k 5 300 python tools/strip_scaling.py 1024 > $OUT/${TAG}_strip_scaling.txt 2>&1; cat $OUT/${TAG}_strip_scaling.txt
 echo "== viewer frames"; timeout -k 5 200 python tools/viewer_frame_bench.py > $OUT/${TAG}_viewer_frames.txt 2>&1; cat $OUT/${TAG}_viewer_frames.txt | cut -c1-200
 echo "== rank rehearsals (gloo, ranks share the card)"
-for n in 2 4 6; do tools/rank_rehearsal.sh $n $OUT/${TAG}_rehearsal_n$n.json 2>&1 | tail -c 600; echo; done
+for n in 2 4 5; do tools/rank_rehearsal.sh $n $OUT/${TAG}_rehearsal_n$n.json 2>&1 | tail -c 600; echo; done
 echo "== fuzz"; timeout -k 10 600 python tools/fuzz_parity.py 1000 > $OUT/${TAG}_fuzz_1000.txt 2>&1; tail -2 $OUT/${TAG}_fuzz_1000.txt
 echo "== done"
