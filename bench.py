@@ -152,6 +152,9 @@ def cpu_baseline(scene, camera, args):
 
 def main():
     args = parse_args()
+    # Every timed frame does ALL its work: the library would otherwise keep the pixels' stored primary hits from one frame to the next
+    # (same camera, same scene: a viewer at rest) and spare the later frames their 0.17 ms pre-pass.
+    os.environ.setdefault("FF_NO_PRIMARY_CACHE", "1")
     import torch
     import torch.distributed as dist
 
@@ -395,6 +398,7 @@ def main():
                 # emitter and stopped at the first certain occluder in front of it
                 "rays_untraversed": int(total_answered / args.steps),
                 "rays_cut_last": int(total_cut / args.steps),
+                "primary_hits_kept_between_frames": os.environ.get("FF_NO_PRIMARY_CACHE") is None,
                 "partition": f"{strip_rows}-row strips round-robin over {world} rank(s)",
                 "gather": gather if gather_note is None else f"{gather} ({gather_note})",
             },

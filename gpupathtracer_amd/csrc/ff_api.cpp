@@ -22,6 +22,7 @@ namespace {
 
 void free_scene(FfState* s)
 {
+    s->primary_valid = s->last_key_valid = false;
     if (s->d_geoms) (void)hipFree(s->d_geoms);
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_normals) (void)hipFree(s->d_normals);
@@ -441,8 +442,31 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const bool pool = s->use_pool && prm->trace_mode == FF_TRACE_BVH && !(s->collect_stats && s->timeline_bucket_us > 0);
     // Every sample of a pixel starts with the same ray (kernel.cu:200-205 has no jitter): a pre-pass traces it once per pixel and the
     // frame's samples start from the stored hit (trace_bvh_kernel).  One slot of 3 x 16 bytes per pixel item.
-    const bool reuse = prm->trace_mode == FF_TRACE_BVH && !debug && spp > 1 && !s->sw.no_primary_reuse;
+    // The stored hits are KEPT: the next frame from the same camera, pixel mapping and scene starts from them without a pre-pass
+    // (a viewer that accumulates 1-spp frames with the camera at rest, kernel.cu:266,342).  A frame of 2 spp or more always runs on
+    // stored hits (the pre-pass pays within the frame: +1.3 % at 2 spp).  A 1-spp frame does when the hits are there already (+8 %),
+    // or when the frame before it had the same key - the camera has come to rest, so this frame's pre-pass (-4 % for this frame) is
+    // the last one; a one-off 1-spp frame traces its primary rays itself (profiles/r04_j_*).
+    const bool reuse_possible = prm->trace_mode == FF_TRACE_BVH && !debug && !s->sw.no_primary_reuse;
+    FfState::PrimaryKey key;
+    std::memset(&key, 0, sizeof key);
+    if (reuse_possible) {
+        std::memcpy(key.cam, k.cam_c0, 16 * sizeof(float));
+        std::memcpy(key.cam + 16, k.cam_pos, 3 * sizeof(float));
+        key.cam[19] = k.far_clip; key.cam[20] = k.screen_w; key.cam[21] = k.screen_h;
+        // (the stored normal is the interpolated one when the frame shades with vertex normals: part of the key)
+        const int dims[12] = { W, H, k.xlim, k.ylim, strip_rows, part, num_parts, local_rows, x0, y0, win_w, k.trinormals != nullptr ? 1 : 0 };
+        std::memcpy(key.dims, dims, sizeof dims);
+        key.pix_items = k.pix_items;
+    }
+    const bool keeping = reuse_possible && !s->sw.no_primary_cache;
+    const bool hits_kept = keeping && s->primary_valid && std::memcmp(&key, &s->primary_key, sizeof key) == 0;
+    const bool at_rest = keeping && s->last_key_valid && std::memcmp(&key, &s->last_key, sizeof key) == 0;
+    const bool reuse = reuse_possible && (spp >= s->sw.reuse_min_spp || hits_kept || at_rest);
+    s->last_key = key;
+    s->last_key_valid = reuse_possible;
     if (reuse) {
+        if (s->primary_cache_bytes < (size_t)3 * (size_t)k.pix_items * sizeof(float4)) s->primary_valid = false; // (the buffer is about to move)
         const int cst = ensure_bytes((void**)&s->d_primary_cache, &s->primary_cache_bytes, (size_t)3 * (size_t)k.pix_items * sizeof(float4));
         if (cst != FF_OK) return cst;
     }
@@ -551,17 +575,28 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     // ... and where a pre-pass stores every pixel's primary hit (below), it marks the pixels that hit NOTHING in the same mask: the
     // exact version of the box test, also for a camera inside the scene's box (an open room seen from within)
     const bool exact_cull = reuse && !s->sw.no_primary_cull && num_blocks - (tail_mode ? 1 : 0) > 0;
+    // Can this frame start from the hits (and the mask) the last one stored?  Same camera, same pixel mapping, no change of the scene
+    // since (every upload / update clears primary_valid), and a mask there if this frame wants one.
+    const bool kept = reuse && hits_kept && (!(cull || exact_cull) || s->primary_has_mask);
+    s->pending_mask_reused = s->pending_mask_built = false;
     if (cull || exact_cull) {
         const size_t mask_bytes = ((size_t)k.pix_items / 64 + 2) * sizeof(unsigned long long);
-        const int mst = ensure_bytes((void**)&s->d_cull_mask, &s->cull_mask_bytes, mask_bytes);
-        if (mst != FF_OK) return mst;
-        if (cull) FF_HIP(launch_cull_mask(k, s->d_cull_mask, st));
-        else FF_HIP(hipMemsetAsync(s->d_cull_mask, 0, mask_bytes, st));
+        if (!kept) {
+            const int mst = ensure_bytes((void**)&s->d_cull_mask, &s->cull_mask_bytes, mask_bytes);
+            if (mst != FF_OK) return mst;
+            if (cull) FF_HIP(launch_cull_mask(k, s->d_cull_mask, st));
+            else FF_HIP(hipMemsetAsync(s->d_cull_mask, 0, mask_bytes, st));
+            s->pending_mask_built = true;
+            if (!reuse) s->primary_has_mask = false; // (the mask that went with the stored hits has just been overwritten; the hits stay)
+        } else {
+            s->pending_mask_reused = true;
+        }
         k.cull_mask = s->d_cull_mask;
         // (a culled pixel's whole-block items are dropped; with a fine-grained tail its last block is still traced sample by sample)
         s->pending_culled_rays_per_pixel = (unsigned)(spp - (tail_mode ? tail_n : 0));
     }
-    if (reuse) {
+    if (reuse && kept) k.primary_hits = s->d_primary_cache;
+    if (reuse && !kept) {
         // The pre-pass: the same persistent kernel, one item per pixel, one primary ray each, the hit stored per pixel (settle_hit).  Its
         // rays are not path segments of the frame: the kernel does not count them, and the work queue starts from zero again behind it.  (Always the lane-
         // owned kernel, never instrumented: the frame's own launches are what the statistics describe.)
@@ -587,6 +622,9 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         FF_HIP(launch_trace(kp, FF_TRACE_BVH, false, grid, block_threads, st, nullptr, false, /*prepass=*/true));
         FF_HIP(hipMemsetAsync(s->d_queue, 0, (size_t)k.queue_counters * kQueueStride * sizeof(unsigned), st));
         k.primary_hits = s->d_primary_cache;
+        s->primary_key = key;
+        s->primary_valid = true;
+        s->primary_has_mask = cull || exact_cull;
     }
     for (int l = 0; l < launches; ++l) {
         k.block_begin = l * blocks_per_launch;
@@ -631,8 +669,15 @@ int render_finish(FfState* s)
     s->stats.rays_traced = 0;
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_traced += s->h_counters[kRaySlotStride * (kRaySlotFirst + j)];
     s->stats.rays_answered = 0;
-    for (int j = 0; j < kRaySlots; ++j) // primary rays of culled pixels
-        s->stats.rays_answered += s->h_counters[kCulledPixelsWord + kRaySlotStride * j] * s->pending_culled_rays_per_pixel;
+    {
+        // the rays of culled pixels: counted by the passes that built the mask - or, for a frame that took the mask over from the
+        // last one, as many pixels as that frame counted
+        unsigned long long culled = 0;
+        for (int j = 0; j < kRaySlots; ++j) culled += s->h_counters[kCulledPixelsWord + kRaySlotStride * j];
+        if (s->pending_mask_reused) culled = s->primary_culled_pixels;
+        else if (s->pending_mask_built) s->primary_culled_pixels = culled;
+        s->stats.rays_answered += culled * s->pending_culled_rays_per_pixel;
+    }
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_answered += s->h_counters[kAnsweredWord + kRaySlotStride * j]; // + repeated primaries
     s->stats.rays_cut_short = 0;
     for (int j = 0; j < kRaySlots; ++j) s->stats.rays_cut_short += s->h_counters[kCutShortWord + kRaySlotStride * j];
@@ -672,6 +717,8 @@ void read_switches(FfState* s)
     w.no_last_bounce_cut = std::getenv("FF_NO_LAST_BOUNCE_CUT") != nullptr;
     w.no_primary_cull = std::getenv("FF_NO_PRIMARY_CULL") != nullptr;
     w.no_primary_reuse = std::getenv("FF_NO_PRIMARY_REUSE") != nullptr;
+    w.no_primary_cache = std::getenv("FF_NO_PRIMARY_CACHE") != nullptr;
+    if (const char* e = std::getenv("FF_REUSE_MIN_SPP")) w.reuse_min_spp = std::max(1, std::atoi(e));
     w.no_any_hit = std::getenv("FF_NO_ANY_HIT") != nullptr;
     if (const char* e = std::getenv("FF_REUSE_QUORUM")) w.reuse_quorum = std::max(1, std::min(65, std::atoi(e)));
     if (const char* e = std::getenv("FF_QUEUE_CHUNK")) w.queue_chunk = std::max(1, std::min(4096, std::atoi(e)));
@@ -957,6 +1004,7 @@ int ff_upload_scene(FfState* s, const FfGeometry* host_geometries, int n)
 {
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_upload_scene: state is null");
+    s->primary_valid = s->last_key_valid = false; // (the stored primary hits belong to the scene that goes)
     const auto t_call = std::chrono::steady_clock::now();
     s->build_stats = FfBuildStats();
     const BvhBuildParams bp = default_bvh_params();
@@ -1071,6 +1119,7 @@ namespace ff {
 int upload_compiled_scene(FfState* s, const CompiledScene& cs, double build_ms)
 {
     const auto t_call = std::chrono::steady_clock::now();
+    s->primary_valid = s->last_key_valid = false;
     s->build_stats = FfBuildStats();
     s->build_stats.build_ms = build_ms;
     const int st = upload_compiled(s, cs);
@@ -1088,6 +1137,7 @@ int ff_update_transforms(FfState* s, const FfGeometry* host_geometries, int n)
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_update_transforms: state is null");
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_update_transforms: no scene uploaded");
+    s->primary_valid = s->last_key_valid = false;
     const auto t_call = std::chrono::steady_clock::now();
     CompiledScene cs;
     int st = compile_scene(host_geometries, n, default_bvh_params(), cs, /*build_bvh=*/false);
@@ -1133,6 +1183,7 @@ int ff_update_mesh(FfState* s, int geometry_index, const FfTriangle* triangles, 
     clear_error();
     if (!s || !triangles) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: null argument");
     if (!s->has_scene) return fail(FF_ERR_NO_SCENE, "ff_update_mesh: no scene uploaded");
+    s->primary_valid = s->last_key_valid = false;
     if (mode != FF_UPDATE_REFIT && mode != FF_UPDATE_REBUILD) return fail(FF_ERR_INVALID_ARG, "ff_update_mesh: unknown mode %d", mode);
     int gi = -1;
     for (size_t i = 0; i < s->h_geoms.size(); ++i)

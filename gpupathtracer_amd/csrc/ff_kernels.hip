@@ -2976,7 +2976,10 @@ __global__ void combine_kernel(const KParams p)
     if (p.x0 + lx >= p.xlim || gy >= p.ylim) return;
     const unsigned pitem = (unsigned)(((ly >> 3) * p.tiles_per_row + (lx >> 3)) * 64 + ((ly & 7) * 8 + (lx & 7)));
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int b = 0; b < p.num_blocks; ++b) {
+    // (a pixel that sees nothing is black whatever its sums hold: a frame that takes the mask over from the last one - same camera, same
+    // scene - runs no pass that zeroes them, and its dropped items wrote none)
+    const bool culled = p.cull_mask != nullptr && ((p.cull_mask[pitem >> 6] >> (pitem & 63u)) & 1ull) != 0ull;
+    for (int b = 0; b < (culled ? 0 : p.num_blocks); ++b) {
         float4 v;
         if (b == p.tail_block) {
             // this block was traced sample by sample: the sequential sum a lane would have kept in registers

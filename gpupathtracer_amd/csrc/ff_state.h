@@ -37,6 +37,20 @@ struct FfState {
     size_t cull_mask_bytes = 0;
     float4* d_primary_cache = nullptr; // KParams::primary_cache
     size_t primary_cache_bytes = 0;
+    // The stored primary hits (and the mask of pixels that see nothing) belong to a camera, a pixel mapping and a scene: while those
+    // stay what they were - a viewer that accumulates 1-spp frames with the camera at rest (kernel.cu:266,342) - the next frame starts
+    // from them without a pre-pass.  primary_key: what they were computed for; any change of the scene clears primary_valid.
+    struct PrimaryKey {
+        float cam[24];
+        int dims[12];
+        unsigned pix_items;
+    } primary_key = {};
+    bool primary_valid = false;
+    PrimaryKey last_key = {};                // the key of the frame before this one, stored hits or not ("has the camera come to rest?")
+    bool last_key_valid = false;
+    bool primary_has_mask = false;           // ... and d_cull_mask holds the mask that goes with them
+    unsigned long long primary_culled_pixels = 0; // pixels marked in it (FfStats::rays_answered of frames that reuse it)
+    bool pending_mask_reused = false, pending_mask_built = false;
     float4* d_park = nullptr;          // KParams::park (job-pool kernel)
     size_t park_bytes = 0;
     int* d_stack_spill = nullptr;         // (stack_entries - stack_lds_levels) x launch threads ints
@@ -95,6 +109,8 @@ struct FfState {
     // getenv runs next to another thread's setenv.
     struct Switches {
         bool no_last_bounce_cut = false, no_primary_cull = false, no_primary_reuse = false; // per frame (render_enqueue)
+        bool no_primary_cache = false; // FF_NO_PRIMARY_CACHE: every frame runs its own pre-pass (the stored hits are not kept from frame to frame)
+        int reuse_min_spp = 2;         // FF_REUSE_MIN_SPP: frames of fewer samples per pixel trace their primary rays themselves unless the hits are there
         bool no_any_hit = false;       // last-bounce queries that hold an emitter stop at the first certain occluder unless set
         int reuse_quorum = 1;
         int queue_chunk = 0, queue_counters = 0; // 0: the library's choice

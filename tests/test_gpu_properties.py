@@ -664,3 +664,76 @@ def test_job_pool_kernel_equals_the_lane_owned_kernel(monkeypatch):
         for i, (a, b) in enumerate(zip(ref, got)):
             assert a[2:5] == b[2:5], (env, i, a[2:5], b[2:5])
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (env, i)
+
+
+def test_stored_primary_hits_are_kept_while_camera_and_scene_stay(monkeypatch):
+    """The pixels' stored primary hits (and the mask of pixels that see nothing) belong to a camera, a pixel mapping and a scene: the
+    next frame from the same ones starts from them without a pre-pass (csrc/ff_api.cpp render_enqueue) - a viewer that accumulates
+    1-spp frames with the camera at rest (kernel.cu:266,342).  Frames rendered that way equal the frames of a state that keeps nothing
+    (FF_NO_PRIMARY_CACHE=1) and the brute-force kernel's, bits and ray / answered counts; a new camera, another frame size, a tile, a
+    transform update and a mesh refit each make the next frame compute its own.  A 1-spp frame starts from stored hits when they are
+    there or when the frame before it had the same camera (it has come to rest: this pre-pass is the last one); a one-off 1-spp frame
+    traces its primary rays itself (FF_REUSE_MIN_SPP=1: every frame runs on stored hits)."""
+    scene = scenes.cornell_wahoo_scene()
+    inside = scenes.posed_camera(160, 96, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    outside = scenes.posed_camera(160, 96, position=(6.0, 2.0, 9.0), yaw=-125.0, pitch=-10.0)
+    steps = [("a", inside, lib.render_params(160, 96, 8, 1, 5)), ("a again", inside, lib.render_params(160, 96, 8, 1, 6)),
+             ("a third", inside, lib.render_params(160, 96, 8, 1, 8)), ("a 70 spp", inside, lib.render_params(160, 96, 4, 70, 7)), ("a smooth", inside, lib.render_params(160, 96, 4, 3, 7, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH_SMOOTH)),
+             ("a flat again", inside, lib.render_params(160, 96, 4, 3, 7)), ("b", outside, lib.render_params(160, 96, 8, 1, 5)),
+             ("b 130 spp", outside, lib.render_params(160, 96, 5, 130, 2)), ("b again", outside, lib.render_params(160, 96, 8, 3, 9)),
+             ("a small", scenes.posed_camera(96, 64, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0), lib.render_params(96, 64, 6, 2, 1)),
+             ("a back", inside, lib.render_params(160, 96, 8, 1, 5))]
+
+    def run(env):
+        for k in ("FF_NO_PRIMARY_CACHE", "FF_REUSE_MIN_SPP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = []
+        with lib.Tracer(0) as t:
+            t.upload_scene(scene)
+            for name, cam, p in steps:
+                rgb8, rad = t.render(cam, p)
+                st = t.stats()
+                out.append((name, rad.view(np.uint32).copy(), st.rays_traced, st.rays_answered))
+            tile = t.render_tile(inside, lib.render_params(160, 96, 4, 2, 3), 40, 24, 80, 48)
+            out.append(("tile", tile[1].view(np.uint32).copy(), 0, 0))
+            full = t.render(inside, lib.render_params(160, 96, 4, 2, 3))
+            out.append(("full after tile", full[1].view(np.uint32).copy(), t.stats().rays_traced, t.stats().rays_answered))
+            assert np.array_equal(out[-2][1], out[-1][1][24:72, 40:120])
+            # the scene moves under a camera at rest: the stored hits go with the old scene
+            shifted = scenes.Scene()
+            shifted.add_mesh(scenes.load_mesh("wahoo"), (0.4, -2.4, 0.3), (0, 25, 0), (0.28, 0.28, 0.28), scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0)))
+            shifted.add_mesh(scenes.load_mesh("cube"), (1.2, -2.0, 0.6), (0, 10, 0), (1, 1, 1), scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(0.75, 0.75, 0.75)))
+            scenes._box(shifted).finalize()
+            t.update_transforms(shifted)
+            upd = t.render(inside, lib.render_params(160, 96, 4, 2, 3))
+            out.append(("after transform update", upd[1].view(np.uint32).copy(), t.stats().rays_traced, t.stats().rays_answered))
+        with lib.Tracer(0) as t2:  # ... a fresh upload of the moved scene renders the same frame
+            t2.upload_scene(shifted)
+            fresh = t2.render(inside, lib.render_params(160, 96, 4, 2, 3))
+            assert np.array_equal(out[-1][1], fresh[1].view(np.uint32)) and out[-1][2] == t2.stats().rays_traced
+        return out
+
+    kept = run({})
+    none = run({"FF_NO_PRIMARY_CACHE": "1"})
+    always = run({"FF_REUSE_MIN_SPP": "1"})
+    by_name = lambda rows: {r[0]: r for r in rows}
+    for a, b, c in zip(kept, none, always):
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2], a[0]
+        assert np.array_equal(a[1], c[1]) and a[2] == c[2], a[0]
+        if a[0] not in ("a", "a again", "a third", "b", "a back"):  # (frames of 2 spp or more run on stored hits in every state)
+            assert a[3] == b[3] == c[3], a[0]
+    # which 1-spp frames started from stored hits: rays_answered counts their primary segments (include/firefly/ff_types.h)
+    k, n, al = by_name(kept), by_name(none), by_name(always)
+    for name in ("a", "b", "a back"):          # one-off frames: primary rays traced by the frame itself
+        assert k[name][3] == n[name][3] < al[name][3], name
+    for name in ("a again", "a third"):        # the camera at rest: pre-pass once, then kept
+        assert k[name][3] == al[name][3] > n[name][3], name
+    with lib.Tracer(0) as t:
+        t.upload_scene(scene)
+        for (name, cam, p), ref in zip(steps, kept):
+            p.trace_mode = T.TRACE_BRUTE_FORCE
+            brute = t.render(cam, p)
+            assert np.array_equal(brute[1].view(np.uint32), ref[1]) and t.stats().rays_traced == ref[2], name
+            p.trace_mode = T.TRACE_BVH

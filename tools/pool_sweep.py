@@ -27,7 +27,7 @@ def isolated(a):
                 if "=" in kv:
                     k, v = kv.split("=", 1)
                     env[k] = v
-            cmd = [sys.executable, os.path.abspath(__file__), "--one", "--scene", a.scene, "--spp", str(a.spp), "--bounces", str(a.bounces), "--size", a.size, "--camera", a.camera, "--reps", "1", c]
+            cmd = [sys.executable, os.path.abspath(__file__), "--one", "--scene", a.scene, "--spp", str(a.spp), "--bounces", str(a.bounces), "--size", a.size, "--camera", a.camera, "--reps", "1", c] + (["--keep-primary-hits"] if a.keep_primary_hits else [])
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in out.stdout.splitlines() if l.startswith("ONE ")]
             if not line:
@@ -46,7 +46,10 @@ def isolated(a):
 
 
 def main():
+    # (like bench.py: every frame runs its own pre-pass unless a configuration says otherwise - FF_NO_PRIMARY_CACHE= with an empty value
+    # is still "set"; use the --keep-primary-hits flag to measure the viewer-at-rest case)
     ap = argparse.ArgumentParser()
+    ap.add_argument("--keep-primary-hits", action="store_true", help="let the library keep the stored primary hits between frames (same camera and scene)")
     ap.add_argument("--scene", default="c2")
     ap.add_argument("--spp", type=int, default=128)
     ap.add_argument("--bounces", type=int, default=8)
@@ -58,6 +61,8 @@ def main():
     ap.add_argument("--one", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("configs", nargs="+")
     a = ap.parse_args()
+    if not a.keep_primary_hits:
+        os.environ.setdefault("FF_NO_PRIMARY_CACHE", "1")
     if a.isolate:
         return isolated(a)
     w, h = (int(v) for v in a.size.split("x"))
@@ -72,7 +77,9 @@ def main():
         c = a.configs[0]
         with lib.Tracer(0) as t:
             t.upload_scene(scene)
-            t.render(cam, params, want_rgb8=False, want_radiance=False)
+            # (hits kept: a one-off frame, the frame that finds the camera at rest and runs the last pre-pass, then the measured one)
+            for _ in range(2 if a.keep_primary_hits else 1):
+                t.render(cam, params, want_rgb8=False, want_radiance=False)
             _, rad = t.render(cam, params, want_rgb8=False)
             st = t.stats()
             print("ONE " + json.dumps({"rate": st.rays_traced / st.kernel_ms / 1e3, "ms": st.kernel_ms, "rays": int(st.rays_traced), "crc": zlib.crc32(rad.tobytes()), "kernel": t.kernel_name()}))
