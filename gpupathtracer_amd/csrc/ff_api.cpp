@@ -747,6 +747,7 @@ int ff_debug_reload_switches(FfState* s)
     clear_error();
     if (!s) return fail(FF_ERR_INVALID_ARG, "ff_debug_reload_switches: state is null");
     read_switches(s);
+    s->primary_valid = s->last_key_valid = false; // (what the stored hits and their mask were computed under may just have changed)
     return FF_OK;
 }
 

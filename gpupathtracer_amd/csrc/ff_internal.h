@@ -149,6 +149,8 @@ struct BvhBuildParams {
     int max_depth = 30;    // hard bound on inner-node depth (the traversal stack is sized from the built depth)
     int bins = 64;
     float c_trav = 1.2f;   // SAH cost of an inner-node visit relative to one triangle test
+    int opt_passes = 1;    // insertion-based optimisation of the finished tree: at most this many passes (0: none; one pass measured best, profiles/r04_m_*)
+    int opt_max_tris = 1 << 18; // ... for meshes of up to this many triangles
 };
 
 // Defaults, overridable for experiments through FF_BVH_LEAF / FF_BVH_BINS / FF_BVH_CTRAV.

@@ -9,10 +9,12 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <queue>
 #include <system_error>
 #include <thread>
 
@@ -269,6 +271,175 @@ struct Builder {
             }
         }
     }
+
+    // ---- insertion-based optimisation of the finished tree (Bittner, Hapala & Havran 2013) ----------------------------------
+    //
+    // The top-down build decides every split with what it knows at that node; afterwards the tree is improved by taking inner
+    // nodes out - the node and its parent disappear, the sibling moves up - and putting the node's two subtrees back where they
+    // add the least surface area to the tree (the area of the new common parent plus what the boxes on the way down to it grow
+    // by), found by a branch-and-bound search from the root.  Passes over all inner nodes, largest first, until a pass gains less
+    // than 0.2 %; the best tree seen that respects max_depth is kept.  Leaves (their triangle ranges) are never touched, so the
+    // triangle records, the leaf sizes and every result stay what they were: the tree only prunes.
+    float inner_area_sum() const
+    {
+        double a = 0.0;
+        for (const BuildNode& n : bn)
+            if (n.left >= 0) a += n.box.half_area();
+        return (float)a;
+    }
+
+    int assign_depths()
+    {
+        int deepest = 0;
+        std::vector<int> todo{ 0 };
+        bn[0].depth = 0;
+        while (!todo.empty()) {
+            const int i = todo.back();
+            todo.pop_back();
+            if (bn[i].left < 0) continue;
+            deepest = std::max(deepest, bn[i].depth + 1);
+            for (int c : { bn[i].left, bn[i].right }) {
+                bn[c].depth = bn[i].depth + 1;
+                todo.push_back(c);
+            }
+        }
+        return deepest;
+    }
+
+    void optimise(int max_passes)
+    {
+        const int n = (int)bn.size();
+        if (max_passes <= 0 || n < 15) return;
+        std::vector<int> parent(n, -1);
+        for (int i = 0; i < n; ++i)
+            if (bn[i].left >= 0) parent[bn[i].left] = parent[bn[i].right] = i;
+        auto refit_up = [&](int i) {
+            for (; i >= 0; i = parent[i]) {
+                Box b = bn[bn[i].left].box;
+                b.grow(bn[bn[i].right].box);
+                bn[i].box = b;
+            }
+        };
+        auto united = [&](const Box& a, const Box& b) {
+            Box u = a;
+            u.grow(b);
+            return u.half_area();
+        };
+        struct Cand {
+            float induced;
+            int node;
+            bool operator<(const Cand& o) const { return induced > o.induced; } // (std::priority_queue pops the largest)
+        };
+        // where subtree x adds the least area (never the root's own place: node 0 stays the root)
+        auto best_place = [&](int x) {
+            const Box& xb = bn[x].box;
+            const float xa = xb.half_area();
+            float best = std::numeric_limits<float>::infinity();
+            int where = -1;
+            std::priority_queue<Cand> q;
+            const float at_root = united(bn[0].box, xb) - bn[0].box.half_area();
+            q.push({ at_root, bn[0].left });
+            q.push({ at_root, bn[0].right });
+            while (!q.empty()) {
+                const Cand c = q.top();
+                q.pop();
+                if (c.induced + xa >= best) break;
+                const float direct = united(bn[c.node].box, xb);
+                if (c.induced + direct < best) {
+                    best = c.induced + direct;
+                    where = c.node;
+                }
+                if (bn[c.node].left >= 0) {
+                    const float below = c.induced + (direct - bn[c.node].box.half_area());
+                    if (below + xa < best) {
+                        q.push({ below, bn[c.node].left });
+                        q.push({ below, bn[c.node].right });
+                    }
+                }
+            }
+            return where;
+        };
+        auto replace_child = [&](int p, int from, int to) {
+            if (bn[p].left == from) bn[p].left = to;
+            else bn[p].right = to;
+            parent[to] = p;
+        };
+        std::vector<BuildNode> best_tree = bn;
+        float best_cost = inner_area_sum();
+        const float first_cost = best_cost;
+        std::vector<int> order;
+        int stale = 0;
+        unsigned long long rng = 0x9E3779B97F4A7C15ull;
+        for (int pass = 0; pass < max_passes; ++pass) {
+            order.clear();
+            for (int i = 1; i < n; ++i)
+                if (bn[i].left >= 0 && parent[i] > 0) order.push_back(i); // (an inner node with a grandparent)
+            if (pass % 2 == 0) {
+                std::sort(order.begin(), order.end(), [&](int a, int b) {
+                    const float aa = bn[a].box.half_area(), ab = bn[b].box.half_area();
+                    return aa > ab || (aa == ab && a < b);
+                });
+            } else {
+                // (every other pass in a scrambled order - a fixed sequence, the tree must not depend on the run: moves that the
+                // largest-first order never tries)
+                for (size_t i = order.size(); i > 1; --i) {
+                    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                    std::swap(order[i - 1], order[(size_t)((rng >> 33) % i)]);
+                }
+            }
+            for (int nd : order) {
+                const int p = parent[nd];
+                if (bn[nd].left < 0 || p <= 0) continue; // (an earlier move of this pass made it a child of the root)
+                const int g = parent[p];
+                const int sib = bn[p].left == nd ? bn[p].right : bn[p].left;
+                replace_child(g, p, sib);
+                refit_up(g);
+                int sub[2] = { bn[nd].left, bn[nd].right };
+                if (bn[sub[0]].box.half_area() < bn[sub[1]].box.half_area()) std::swap(sub[0], sub[1]);
+                const int spare[2] = { nd, p };
+                for (int k = 0; k < 2; ++k) {
+                    const int x = sub[k], f = spare[k];
+                    const int at = best_place(x);
+                    const int ap = parent[at];
+                    replace_child(ap, at, f);
+                    bn[f].left = at;
+                    bn[f].right = x;
+                    parent[at] = parent[x] = f;
+                    refit_up(f);
+                }
+            }
+            const float cost = inner_area_sum();
+            const bool fits = assign_depths() <= P.max_depth;
+            if (fits && cost < best_cost) {
+                stale = cost > best_cost * 0.999f ? stale + 1 : 0;
+                best_cost = cost;
+                best_tree = bn;
+            } else {
+                ++stale;
+            }
+            if (stale >= 3) break;
+        }
+        if (std::getenv("FF_BVH_OPT_VERBOSE")) std::fprintf(stderr, "[ff] tree of %d nodes: inner area %.6g -> %.6g\n", n, (double)first_cost, (double)best_cost);
+        bn = best_tree;
+        assign_depths();
+        // triangles back in leaf order (depth first): neighbouring leaves keep neighbouring records
+        std::vector<int> new_perm;
+        new_perm.reserve(perm.size());
+        std::vector<int> todo{ 0 };
+        while (!todo.empty()) {
+            const int i = todo.back();
+            todo.pop_back();
+            if (bn[i].left < 0) {
+                const int start = (int)new_perm.size();
+                for (int k = 0; k < bn[i].count; ++k) new_perm.push_back(perm[bn[i].start + k]);
+                bn[i].start = start;
+            } else {
+                todo.push_back(bn[i].right);
+                todo.push_back(bn[i].left);
+            }
+        }
+        perm.swap(new_perm);
+    }
 };
 
 } // namespace
@@ -279,6 +450,7 @@ BvhBuildParams default_bvh_params()
     if (const char* e = std::getenv("FF_BVH_LEAF")) p.max_leaf_tris = std::max(1, std::min(8, std::atoi(e)));
     if (const char* e = std::getenv("FF_BVH_BINS")) p.bins = std::max(4, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("FF_BVH_CTRAV")) p.c_trav = (float)std::atof(e);
+    if (const char* e = std::getenv("FF_BVH_OPT_PASSES")) p.opt_passes = std::max(0, std::min(1000, std::atoi(e)));
     return p;
 }
 
@@ -291,6 +463,7 @@ int build_mesh_bvh(const FfTriangle* triangles, int count, const BvhBuildParams&
     }
     Builder B(triangles, count, params);
     B.build();
+    if (count <= params.opt_max_tris) B.optimise(params.opt_passes);
 
     // Conservative padding: the triangle test accepts hits whose geometric miss distance is a few ulps of the
     // coordinates involved; boxes are grown by 1e-4 of the mesh's largest |coordinate| (>> those ulps) so that every

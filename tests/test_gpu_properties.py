@@ -681,6 +681,7 @@ def test_stored_primary_hits_are_kept_while_camera_and_scene_stay(monkeypatch):
              ("a third", inside, lib.render_params(160, 96, 8, 1, 8)), ("a 70 spp", inside, lib.render_params(160, 96, 4, 70, 7)), ("a smooth", inside, lib.render_params(160, 96, 4, 3, 7, T.TRACE_BVH, T.SHADE_DIFFUSE_PATH_SMOOTH)),
              ("a flat again", inside, lib.render_params(160, 96, 4, 3, 7)), ("b", outside, lib.render_params(160, 96, 8, 1, 5)),
              ("b 130 spp", outside, lib.render_params(160, 96, 5, 130, 2)), ("b again", outside, lib.render_params(160, 96, 8, 3, 9)),
+             ("b 200 spp", outside, lib.render_params(160, 96, 3, 200, 4)),  # (a fine-grained tail: the last block sample by sample, mask kept)
              ("a small", scenes.posed_camera(96, 64, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0), lib.render_params(96, 64, 6, 2, 1)),
              ("a back", inside, lib.render_params(160, 96, 8, 1, 5))]
 
