@@ -533,8 +533,18 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     // It costs a per-sample buffer (2.1 GB written and read back at 1080p), which the 1 024-spp one-GPU frame does not earn back
     // (+0.4 %, and 4x its HBM traffic): off there.  FF_TAIL_GROUP forces it (with that group size) wherever a launch has
     // FF_TAIL_MIN_BLOCKS blocks.  Frames whose buffer would pass 16 GiB render without it (FfStats::flags).
-    const int tail_n = spp - (num_blocks - 1) * block_spp; // samples of the frame's last block
     const bool short_frame = num_parts == 1 && !s->tail_forced && num_blocks <= 8;
+    // How many of the frame's last blocks go out that way.  A lane that takes one of the last WHOLE blocks finishes up to two block
+    // times later (path lengths vary by that much between pixels); the short items must last that long for the launch to end on
+    // them, so a rank's strips - where a block time is 6 % of the launch - hand out TWO blocks in groups (r04: eight ranks 94.7 ->
+    // see profiles/r04_n_*).  The kernels see one "tail block" of up to 2 x block_spp samples starting at block tail_block; the
+    // combine pass adds each block's samples in order.
+    // (two where a lane gets fewer than 24 whole blocks in the launch - eight ranks at 1080p and 1 024 spp: 16 -, one where it gets
+    // more: there the short items' own overhead outweighs the shorter end, 4 ranks 97.7 -> 97.3 %, 2 ranks 98.9 -> 98.5 %)
+    const double blocks_per_lane = (double)k.pix_items * (double)last_launch_blocks / ((double)grid * (double)block_threads);
+    const int tail_blocks_wanted = s->sw.tail_blocks > 0 ? s->sw.tail_blocks : (num_parts > 1 && blocks_per_lane < 24.0 ? 2 : 1);
+    const int tail_blocks = std::max(1, std::min(std::min(tail_blocks_wanted, 3), last_launch_blocks - 1));
+    const int tail_n = spp - (num_blocks - tail_blocks) * block_spp; // samples of the frame's last block(s)
     // group size: the given one (multi-part frames: 32 samples), scaled with the block size beyond 1 024 spp and at least an
     // eighth of the block; short one-GPU frames: a quarter of the block, at least 4 samples
     const int tail_step = short_frame ? std::max(4, (tail_n + 3) / 4) : std::max(s->tail_group_spp * (block_spp / 64), (tail_n + 7) / 8);
@@ -571,10 +581,10 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     // item costs the queue what its 16 samples cost a lane that starts them from a stored miss; no gain, profiles/r04_f_*)
     // (... and so does the reference's own frame - one primary ray per pixel, shaded by its normal: tracing a ray that misses
     // everything costs what the mask pass costs, and the pass is a second launch: 0.089 instead of 0.064 ms at 1080p)
-    cull = cull && num_blocks - (tail_mode ? 1 : 0) > 0 && !debug;
+    cull = cull && num_blocks - (tail_mode ? tail_blocks : 0) > 0 && !debug;
     // ... and where a pre-pass stores every pixel's primary hit (below), it marks the pixels that hit NOTHING in the same mask: the
     // exact version of the box test, also for a camera inside the scene's box (an open room seen from within)
-    const bool exact_cull = reuse && !s->sw.no_primary_cull && num_blocks - (tail_mode ? 1 : 0) > 0;
+    const bool exact_cull = reuse && !s->sw.no_primary_cull && num_blocks - (tail_mode ? tail_blocks : 0) > 0;
     // Can this frame start from the hits (and the mask) the last one stored?  Same camera, same pixel mapping, no change of the scene
     // since (every upload / update clears primary_valid), and a mask there if this frame wants one.
     const bool kept = reuse && hits_kept && (!(cull || exact_cull) || s->primary_has_mask);
@@ -633,8 +643,8 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         k.total_items = k.pix_items * k.whole_blocks;
         if (tail_mode && l == launches - 1) {
             const unsigned groups = (unsigned)k.tail_groups;
-            k.tail_block = num_blocks - 1;
-            k.whole_blocks = (unsigned)(k.block_end - 1 - k.block_begin);
+            k.tail_block = num_blocks - tail_blocks;
+            k.whole_blocks = (unsigned)(k.block_end - tail_blocks - k.block_begin);
             k.tail_first_item = k.pix_items * k.whole_blocks;
             k.total_items = k.tail_first_item + k.pix_items * groups;
         }
@@ -718,6 +728,7 @@ void read_switches(FfState* s)
     w.no_primary_cull = std::getenv("FF_NO_PRIMARY_CULL") != nullptr;
     w.no_primary_reuse = std::getenv("FF_NO_PRIMARY_REUSE") != nullptr;
     w.no_primary_cache = std::getenv("FF_NO_PRIMARY_CACHE") != nullptr;
+    if (const char* e = std::getenv("FF_TAIL_BLOCKS")) w.tail_blocks = std::max(1, std::min(3, std::atoi(e)));
     if (const char* e = std::getenv("FF_REUSE_MIN_SPP")) w.reuse_min_spp = std::max(1, std::atoi(e));
     w.no_any_hit = std::getenv("FF_NO_ANY_HIT") != nullptr;
     if (const char* e = std::getenv("FF_REUSE_QUORUM")) w.reuse_quorum = std::max(1, std::min(65, std::atoi(e)));

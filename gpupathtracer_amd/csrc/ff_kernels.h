@@ -71,10 +71,10 @@ struct KParams {
     // tail_group_spp samples) items that store every sample's radiance separately; the combine pass adds that block's
     // samples in order, which is bit for bit what a lane summing the block in registers computes.  The launch then runs
     // dry on 16-sample items instead of 64-sample ones (a 14 ms tail per launch on the benchmark frame otherwise).
-    int tail_block;          // global index of the block handled that way
+    int tail_block;          // global index of the (first) block handled that way: one block, or the frame's last two as one run of samples
     int tail_groups;         // tail items per pixel; group g covers the block's samples [tail_start[g], tail_start[g + 1])
     int tail_start[9];
-    int tail_samples_in_block; // samples the tail block holds (the frame's last block may be partial)
+    int tail_samples_in_block; // samples stored that way: those of the frame's last block (it may be partial), or of its last two
     unsigned tail_first_item; // queue index of the first tail item of this launch
     float4* tail_samples;    // [block_spp][pix_items] per-sample radiance of the tail block
     unsigned long long* counters; // [0] queries cut short by the traversal loop guard (must stay 0) [1] inner-node visits [2] triangle tests [3] plane tests (rays: the slots below)

@@ -2981,11 +2981,13 @@ __global__ void combine_kernel(const KParams p)
     const bool culled = p.cull_mask != nullptr && ((p.cull_mask[pitem >> 6] >> (pitem & 63u)) & 1ull) != 0ull;
     for (int b = 0; b < (culled ? 0 : p.num_blocks); ++b) {
         float4 v;
-        if (b == p.tail_block) {
-            // this block was traced sample by sample: the sequential sum a lane would have kept in registers
+        if (p.tail_block >= 0 && b >= p.tail_block) {
+            // this block was traced sample by sample (the frame's last block, or its last two): the sequential sum a lane would have
+            // kept in registers.  The stored samples are numbered from the first of those blocks on.
             float bx = 0.f, by = 0.f, bz = 0.f;
             const float4* sp = p.tail_samples + pitem; // sample-major: neighbouring threads read neighbouring values
-            for (int i = 0; i < p.tail_samples_in_block; ++i) {
+            const int first = (b - p.tail_block) * p.block_spp, past = min(p.tail_samples_in_block, first + p.block_spp);
+            for (int i = first; i < past; ++i) {
                 const float4 l = sp[(size_t)i * p.pix_items];
                 bx = bx + l.x;
                 by = by + l.y;

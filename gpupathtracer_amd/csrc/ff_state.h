@@ -110,6 +110,7 @@ struct FfState {
     struct Switches {
         bool no_last_bounce_cut = false, no_primary_cull = false, no_primary_reuse = false; // per frame (render_enqueue)
         bool no_primary_cache = false; // FF_NO_PRIMARY_CACHE: every frame runs its own pre-pass (the stored hits are not kept from frame to frame)
+        int tail_blocks = 0;           // FF_TAIL_BLOCKS: how many of the frame's last sample blocks go out as short items (0: the library's choice)
         int reuse_min_spp = 2;         // FF_REUSE_MIN_SPP: frames of fewer samples per pixel trace their primary rays themselves unless the hits are there
         bool no_any_hit = false;       // last-bounce queries that hold an emitter stop at the first certain occluder unless set
         int reuse_quorum = 1;

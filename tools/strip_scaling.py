@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpupathtracer_amd import lib, scenes, dist
 
+os.environ.setdefault("FF_NO_PRIMARY_CACHE", "1")  # (like bench.py: every timed frame pays for its own pre-pass)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 scene = scenes.cornell_wahoo_scene()
 cam = scenes.posed_camera(1920, 1080, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
