@@ -340,7 +340,9 @@ struct Builder {
             const float at_root = united(bn[0].box, xb) - bn[0].box.half_area();
             q.push({ at_root, bn[0].left });
             q.push({ at_root, bn[0].right });
-            while (!q.empty()) {
+            // (a search that cannot prune - thousands of boxes on top of each other - settles for the best of its first 4 096
+            // candidates: any place is a valid place, and the pass stays linear in the size of the tree)
+            for (int visited = 0; !q.empty() && visited < 4096; ++visited) {
                 const Cand c = q.top();
                 q.pop();
                 if (c.induced + xa >= best) break;
@@ -1052,6 +1054,16 @@ extern "C" int ff_scene_info(const FfGeometry* host_geometries, int n, FfSceneIn
     int max_leaf = 0;
     out->valid = check_bvh(cs, &max_leaf) ? 1 : 0;
     out->bvh_max_leaf = max_leaf;
+    double area = 0.0;
+    for (const BvhNode& nd : cs.nodes) {
+        const float* lo[2] = { nd.lmin, nd.rmin };
+        const float* hi[2] = { nd.lmax, nd.rmax };
+        for (int c = 0; c < 2; ++c) {
+            const double dx = (double)hi[c][0] - lo[c][0], dy = (double)hi[c][1] - lo[c][1], dz = (double)hi[c][2] - lo[c][2];
+            if (dx >= 0.0 && dy >= 0.0 && dz >= 0.0) area += dx * dy + dy * dz + dz * dx;
+        }
+    }
+    out->bvh_child_area = (float)area;
     return FF_OK;
 }
 

@@ -141,7 +141,7 @@ class FfSceneInfo(C.Structure):
         ("bvh_nodes", C.c_int32), ("bvh_max_depth", C.c_int32), ("bvh_max_leaf", C.c_int32),
         ("lds_nodes", C.c_int32), ("lds_bytes", C.c_int32),
         ("num_triangles", C.c_uint64), ("device_bytes", C.c_uint64),
-        ("valid", C.c_int32), ("_reserved", C.c_int32),
+        ("valid", C.c_int32), ("bvh_child_area", C.c_float),
     ]
 
 

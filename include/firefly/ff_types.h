@@ -218,7 +218,8 @@ typedef struct FfSceneInfo {
     uint64_t num_triangles;
     uint64_t device_bytes;     /* total device bytes of the compiled scene */
     int32_t  valid;            /* 1 if the structural self-check passed (every triangle in exactly one leaf, boxes enclose) */
-    int32_t  _reserved;
+    float    bvh_child_area;   /* summed half surface area of every child box of the binary trees (object space, padded): what the
+                                  SAH build and the insertion-based optimisation pass reduce */
 } FfSceneInfo;
 
 #ifdef __cplusplus
