@@ -294,6 +294,26 @@ def test_fine_grained_tail_is_bit_identical(monkeypatch):
             _, rad = t.render_strips(cam, p300, 4, part, 3)
             rows = ffdist.strip_row_indices(90, 4, part, 3)
             assert np.array_equal(rad.view(np.uint32), full[rows].view(np.uint32)), part
+    # ... whether the frame's last one, two or three sample blocks go out as short items (csrc/ff_api.cpp: two where a rank's launch is
+    # short, FF_TAIL_BLOCKS forces a number; a partial last block, and a frame all of whose blocks are tail blocks)
+    for blocks in ("1", "2", "3"):
+        monkeypatch.setenv("FF_TAIL_BLOCKS", blocks)
+        with lib.Tracer(0) as t:
+            t.upload_scene(scene)
+            for spp in (300, 256, 100):
+                ref = out[("0", spp)][1] if ("0", spp) in out else None
+                if ref is None:
+                    monkeypatch.setenv("FF_TAIL_GROUP", "0")
+                    with lib.Tracer(0) as t0:
+                        t0.upload_scene(scene)
+                        ref = t0.render(cam, lib.render_params(160, 90, 5, spp, 77))[1]
+                    monkeypatch.delenv("FF_TAIL_GROUP")
+                for part in range(2):
+                    _, rad = t.render_strips(cam, lib.render_params(160, 90, 5, spp, 77), 8, part, 2)
+                    assert t.stats().flags & T.FF_STATS_TAIL_ITEMS or spp == 100, (blocks, spp)
+                    rows = ffdist.strip_row_indices(90, 8, part, 2)
+                    assert np.array_equal(rad.view(np.uint32), ref[rows].view(np.uint32)), (blocks, spp, part)
+    monkeypatch.delenv("FF_TAIL_BLOCKS")
     small = scenes.posed_camera(12, 9, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
     p = lib.render_params(12, 9, 4, 300, 5)  # five blocks, the last one holds 44 samples
     with lib.Tracer(0) as t:
