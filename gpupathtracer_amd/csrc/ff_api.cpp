@@ -536,8 +536,8 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const bool short_frame = num_parts == 1 && !s->tail_forced && num_blocks <= 8;
     // How many of the frame's last blocks go out that way.  A lane that takes one of the last WHOLE blocks finishes up to two block
     // times later (path lengths vary by that much between pixels); the short items must last that long for the launch to end on
-    // them, so a rank's strips - where a block time is 6 % of the launch - hand out TWO blocks in groups (r04: eight ranks 94.7 ->
-    // see profiles/r04_n_*).  The kernels see one "tail block" of up to 2 x block_spp samples starting at block tail_block; the
+    // them, so a rank's strips - where a block time is 6 % of the launch - hand out TWO blocks in groups (eight ranks 94.5 -> 96 % of
+    // ideal, profiles/r04_n_*).  The kernels see one "tail block" of up to 2 x block_spp samples starting at block tail_block; the
     // combine pass adds each block's samples in order.
     // (two where a lane gets fewer than 24 whole blocks in the launch - eight ranks at 1080p and 1 024 spp: 16 -, one where it gets
     // more: there the short items' own overhead outweighs the shorter end, 4 ranks 97.7 -> 97.3 %, 2 ranks 98.9 -> 98.5 %)
@@ -730,7 +730,6 @@ void read_switches(FfState* s)
     w.no_primary_cache = std::getenv("FF_NO_PRIMARY_CACHE") != nullptr;
     if (const char* e = std::getenv("FF_TAIL_BLOCKS")) w.tail_blocks = std::max(1, std::min(3, std::atoi(e)));
     if (const char* e = std::getenv("FF_REUSE_MIN_SPP")) w.reuse_min_spp = std::max(1, std::atoi(e));
-    w.no_any_hit = std::getenv("FF_NO_ANY_HIT") != nullptr;
     if (const char* e = std::getenv("FF_REUSE_QUORUM")) w.reuse_quorum = std::max(1, std::min(65, std::atoi(e)));
     if (const char* e = std::getenv("FF_QUEUE_CHUNK")) w.queue_chunk = std::max(1, std::min(4096, std::atoi(e)));
     if (const char* e = std::getenv("FF_QUEUE_COUNTERS")) w.queue_counters = std::max(1, std::min(kQueueCounters, std::atoi(e)));

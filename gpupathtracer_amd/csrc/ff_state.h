@@ -112,7 +112,6 @@ struct FfState {
         bool no_primary_cache = false; // FF_NO_PRIMARY_CACHE: every frame runs its own pre-pass (the stored hits are not kept from frame to frame)
         int tail_blocks = 0;           // FF_TAIL_BLOCKS: how many of the frame's last sample blocks go out as short items (0: the library's choice)
         int reuse_min_spp = 2;         // FF_REUSE_MIN_SPP: frames of fewer samples per pixel trace their primary rays themselves unless the hits are there
-        bool no_any_hit = false;       // last-bounce queries that hold an emitter stop at the first certain occluder unless set
         int reuse_quorum = 1;
         int queue_chunk = 0, queue_counters = 0; // 0: the library's choice
         int queue_tail = -1;           // FF_QUEUE_TAIL: items per wave in the as-asked tail zone of the work queue (-1: the library's choice, 0: off)
