@@ -203,7 +203,7 @@ def main():
     tracer.upload_scene(scene)
     tracer.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    strip_rows = lib.dist_strip_rows(world) if world > 1 else args.height
+    strip_rows = lib.dist_strip_rows(world, args.height) if world > 1 else args.height
     local_rows = tracer.strips_local_rows(args.height, strip_rows, rank, world)
     # N > 1: every rank renders its strips, rank 0 gathers them behind the C ABI (ff_render_distributed: packed strips, one
     # grouped ncclSend / ncclRecv over RCCL, one scatter kernel).  torch.distributed only carries the 128-byte RCCL id here.

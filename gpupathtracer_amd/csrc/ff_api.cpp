@@ -547,7 +547,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
     const int tail_n = spp - (num_blocks - tail_blocks) * block_spp; // samples of the frame's last block(s)
     // group size: the given one (multi-part frames: 32 samples), scaled with the block size beyond 1 024 spp and at least an
     // eighth of the block; short one-GPU frames: a quarter of the block, at least 4 samples
-    const int tail_step = short_frame ? std::max(4, (tail_n + 3) / 4) : std::max(s->tail_group_spp * (block_spp / 64), (tail_n + 7) / 8);
+    const int tail_step = short_frame ? std::max(4, (tail_n + 3) / 4) : std::max(s->tail_group_spp * (block_spp / 64), (tail_n + 15) / 16);
     const bool tail_wanted = !debug && prm->trace_mode == FF_TRACE_BVH && s->tail_group_spp > 0 && tail_step < tail_n &&
                              (short_frame || ((num_parts > 1 || s->tail_forced) && last_launch_blocks >= s->tail_min_blocks));
     const size_t tail_bytes = (size_t)k.pix_items * (size_t)tail_n * sizeof(float4); // [sample of the block][pixel item]
@@ -573,7 +573,7 @@ int render_enqueue(FfState* s, const FfCamera* camera, const FfRenderParams* prm
         // than the tail they save, 92.3 % instead of 93.3 % of ideal at eight ranks.)
         int g = 0;
         k.tail_start[0] = 0;
-        while (k.tail_start[g] < tail_n && g < 8) { k.tail_start[g + 1] = std::min(tail_n, k.tail_start[g] + tail_step); ++g; }
+        while (k.tail_start[g] < tail_n && g < 16) { k.tail_start[g + 1] = std::min(tail_n, k.tail_start[g] + tail_step); ++g; }
         k.tail_groups = g;
     }
     // (after the tail decision: the tail block's samples are stored one by one and are not part of the cull - a frame whose only

@@ -110,11 +110,26 @@ struct PackLayout {
     size_t total_bytes() const { return part_offset(num_parts); }
 };
 
-int default_strip_rows(int world)
+// Strip height for `world` parts of a frame of `height` rows: the one - of 1 .. 16 rows - whose LARGEST part has the fewest rows, the
+// thinnest such of at least two rows if there is one.  1080 rows: 2-row strips for 2 or 4 ranks, 3-row strips for 8 (135 rows each); with the
+// 16 / 8 / 4-row strips of rounds 2-3 six of eight ranks had 136 rows and two had 132, and the slowest rank sets the frame time
+// (same box, tools/strip_scaling.py: 98.9 / 97.4 / 96.4 -> 99.5 / 99.1 / 97.5 % of ideal with the 8-sample tail items that went in
+// with it, profiles/r04_p_*).  Thin strips also deal neighbouring rows - similar cost - to different ranks.
+int default_strip_rows(int world, int height)
 {
-    // thin strips for many ranks: every rank then holds the same number of rows to within one strip, and neighbouring
-    // strips (similar cost) go to different ranks (1080 rows over 8 ranks: 4-row strips -> 136 or 132 rows per rank)
-    return world <= 2 ? 16 : (world <= 4 ? 8 : 4);
+    if (world <= 1 || height <= 0) return 16;
+    int best = 16;
+    long best_rows = -1;
+    for (int s = 16; s >= 1; --s) {
+        long worst = 0;
+        for (int p = 0; p < world; ++p) worst = std::max<long>(worst, ff_strips_local_rows(height, s, p, world));
+        // (descending: on equal rows the thinner strip replaces the thicker one, except that a 1-row strip only wins outright)
+        if (best_rows < 0 || worst < best_rows || (worst == best_rows && s >= 2)) {
+            best_rows = worst;
+            best = s;
+        }
+    }
+    return best;
 }
 
 // Device buffers for the frame's final outputs on the gathering device when the caller passed host pointers (or null).
@@ -332,7 +347,8 @@ int ff_debug_dist_fail_rank(FfState* s, int rank)
     return FF_OK;
 }
 
-int ff_dist_strip_rows(int world_size) { return default_strip_rows(world_size < 1 ? 1 : world_size); }
+int ff_dist_strip_rows(int world_size) { return default_strip_rows(world_size < 1 ? 1 : world_size, 1080); }
+int ff_dist_strip_rows_for(int height, int world_size) { return default_strip_rows(world_size < 1 ? 1 : world_size, height); }
 
 // The wire layout of the gather (PackLayout), for callers and tests: the message part `part` sends to rank 0 and where it lands
 // in rank 0's gather buffer.  A part without rows has no message: neither side posts one (the same predicate on both sides).
@@ -382,7 +398,7 @@ int ff_render_distributed(FfState* s, const FfCamera* camera, const FfRenderPara
     int local = check_render_call(s, camera, params, "ff_render_distributed");
     if (local == FF_OK && d->fail_rank == rank) local = fail(FF_ERR_OOM, "injected failure on rank %d (FF_DEBUG_DIST_FAIL_RANK)", rank);
     if (local == FF_OK) {
-        if (strip_rows <= 0) strip_rows = default_strip_rows(world);
+        if (strip_rows <= 0) strip_rows = default_strip_rows(world, params->height);
         L.width = params->width;
         L.height = params->height;
         L.strip_rows = strip_rows;
@@ -584,7 +600,7 @@ int multi_render_core(FfMulti* m, const FfCamera* camera, const FfRenderParams* 
         m->stats = root->stats;
         return st;
     }
-    if (strip_rows <= 0) strip_rows = default_strip_rows(n);
+    if (strip_rows <= 0) strip_rows = default_strip_rows(n, params->height);
     PackLayout L;
     L.width = params->width;
     L.height = params->height;

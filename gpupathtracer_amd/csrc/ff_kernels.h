@@ -73,7 +73,7 @@ struct KParams {
     // dry on 16-sample items instead of 64-sample ones (a 14 ms tail per launch on the benchmark frame otherwise).
     int tail_block;          // global index of the (first) block handled that way: one block, or the frame's last two as one run of samples
     int tail_groups;         // tail items per pixel; group g covers the block's samples [tail_start[g], tail_start[g + 1])
-    int tail_start[9];
+    int tail_start[17];
     int tail_samples_in_block; // samples stored that way: those of the frame's last block (it may be partial), or of its last two
     unsigned tail_first_item; // queue index of the first tail item of this launch
     float4* tail_samples;    // [block_spp][pix_items] per-sample radiance of the tail block

@@ -89,7 +89,7 @@ struct FfState {
     size_t tail_samples_bytes = 0;
     bool tail_forced = false; // FF_TAIL_GROUP given: the fine-grained tail also for one-part frames
     int tail_min_blocks = 4;  // launches with fewer sample blocks keep whole-block items (FF_TAIL_MIN_BLOCKS)
-    int tail_group_spp = 16; // FF_TAIL_GROUP (0 = off): samples per tail item of a multi-part frame.  With the chunked work queue 16 beats 32
+    int tail_group_spp = 8;  // FF_TAIL_GROUP (0 = off): samples per tail item of a multi-part frame.  8 since the samples start from stored hits (r04: eight ranks +0.5, four +0.7 points; rounds 2-3: 16)
                              // (slowest of 8 ranks at 95.6 % of full-frame time / 8 instead of 93.8 %, of 4 ranks 97.4 / 96.7: tools/strip_scaling.py)
     // progressive accumulation (ff_render_progressive)
     float* d_accum = nullptr;

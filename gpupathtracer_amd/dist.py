@@ -10,10 +10,17 @@ import numpy as np
 STRIP_ROWS = 16  # the reference's block height (kernel.cu:306); strips of 16 rows are dealt round-robin to ranks
 
 
-def strip_rows_for(world_size):
-    """Strip height used by the benchmark: 16 rows for 2 ranks, thinner strips for more ranks so that every rank gets the
-    same number of rows to within one strip (1080 rows over 8 ranks: 4-row strips -> 136 or 132 rows per rank)."""
-    return 16 if world_size <= 2 else (8 if world_size <= 4 else 4)
+def strip_rows_for(world_size, height=1080):
+    """Strip height used by the benchmark (mirrors ff_dist_strip_rows_for): of 1 .. 16 rows the one whose largest part has the
+    fewest rows, the thinnest such of at least two rows (1080 rows: 2-row strips for 2 and 4 ranks, 3-row strips for 8: equal shares)."""
+    if world_size <= 1 or height <= 0:
+        return 16
+    best, best_rows = 16, None
+    for s in range(16, 0, -1):
+        worst = max(strip_layout(height, s, world_size))
+        if best_rows is None or worst < best_rows or (worst == best_rows and s >= 2):
+            best, best_rows = s, worst
+    return best
 
 
 def strip_layout(height, strip_rows, num_parts):

@@ -23,7 +23,7 @@ EXPORTS = [
     "ff_render_progressive", "ff_render_to_pbo_progressive", "ff_save_ppm",
     "ff_set_collect_stats", "ff_stats", "ff_debug_kernel_name", "ff_debug_counters", "ff_debug_timeline", "ff_debug_check_ieee", "ff_debug_reload_switches", "ff_load_obj", "ff_free_triangles",
     "ff_scene_file_load", "ff_scene_file_geometries", "ff_scene_file_camera", "ff_scene_file_free",
-    "ff_dist_unique_id", "ff_dist_init", "ff_dist_available", "ff_dist_shutdown", "ff_dist_strip_rows", "ff_dist_part_bytes", "ff_render_distributed", "ff_debug_dist_fail_rank",
+    "ff_dist_unique_id", "ff_dist_init", "ff_dist_available", "ff_dist_shutdown", "ff_dist_strip_rows", "ff_dist_strip_rows_for", "ff_dist_part_bytes", "ff_render_distributed", "ff_debug_dist_fail_rank",
     "ff_multi_create", "ff_multi_destroy", "ff_multi_count", "ff_multi_state", "ff_multi_uses_rccl", "ff_multi_upload_scene",
     "ff_multi_render", "ff_multi_render_to_pbo", "ff_multi_stats",
 ]
@@ -129,6 +129,7 @@ def load():
     lib.ff_debug_dist_fail_rank.argtypes = [vp, C.c_int]
     lib.ff_dist_available.argtypes = []
     lib.ff_dist_strip_rows.argtypes = [i32]
+    lib.ff_dist_strip_rows_for.argtypes = [i32, i32]
     lib.ff_dist_part_bytes.argtypes = [i32, i32, i32, i32, i32, P(C.c_longlong)]
     lib.ff_dist_part_bytes.restype = C.c_longlong
     lib.ff_render_distributed.argtypes = [vp, P(T.FfCamera), P(T.FfRenderParams), i32, vp, i32, vp, i32]
@@ -441,8 +442,8 @@ def dist_available():
     return load().ff_dist_available() == T.FF_OK
 
 
-def dist_strip_rows(world_size):
-    return load().ff_dist_strip_rows(world_size)
+def dist_strip_rows(world_size, height=1080):
+    return load().ff_dist_strip_rows_for(height, world_size)
 
 
 class MultiTracer:

@@ -190,7 +190,10 @@ FF_API int ff_dist_init(FfState* state, int rank, int world_size, const void* id
 FF_API int ff_dist_available(void);
 FF_API int ff_dist_shutdown(FfState* state);
 
-/* Strip height the distributed renderers use when given strip_rows <= 0: 16 rows for up to 2 GPUs, 8 up to 4, else 4. */
+/* Strip height the distributed renderers use when given strip_rows <= 0: of 1 .. 16 rows the height whose largest part has the
+ * fewest rows (the slowest rank sets the frame time), the thinnest such of at least two rows: for 1080 rows 2-row strips over 2 or 4 GPUs, 3-row strips over 8
+ * (equal shares: 135 rows each there).  ff_dist_strip_rows(world) is ff_dist_strip_rows_for(1080, world). */
+FF_API int ff_dist_strip_rows_for(int height, int world_size);
 FF_API int ff_dist_strip_rows(int world_size);
 
 /* The gather's wire layout: bytes of the ONE message part `part` sends to rank 0 (its rows as float3 radiance, then as rgb8,

@@ -62,6 +62,21 @@ def test_strip_layout_matches_library(ff):
         assert sorted(allrows.tolist()) == list(range(h))
 
 
+def test_default_strip_height_balances_the_parts(ff):
+    """ff_dist_strip_rows_for (csrc/ff_dist.cpp default_strip_rows; mirrored by dist.strip_rows_for): the strip height - 1 .. 16 rows -
+    whose largest part has the fewest rows, the thinnest such of at least two rows.  The slowest rank sets the frame time: 1080 rows
+    over 2, 4 or 8 ranks come out at equal shares (2-row strips for 2 and 4 ranks, 3-row strips for 8: 135 rows each, not 136 and 132)."""
+    lib = ff.load()
+    for h in (1080, 2160, 720, 800, 1, 17, 1000):
+        for n in (1, 2, 3, 4, 5, 8):
+            s = lib.ff_dist_strip_rows_for(h, n)
+            assert s == ffdist.strip_rows_for(n, h) and 1 <= s <= 16
+            worst = max(ffdist.strip_layout(h, s, n))
+            assert worst == min(max(ffdist.strip_layout(h, t, n)) for t in range(1, 17)), (h, n, s)
+    assert [lib.ff_dist_strip_rows_for(1080, n) for n in (2, 4, 8)] == [2, 2, 3] and lib.ff_dist_strip_rows(8) == 3
+    assert ffdist.strip_layout(1080, 3, 8) == [135] * 8 and ffdist.strip_layout(1080, 2, 4) == [270] * 4
+
+
 def test_gather_wire_layout_and_parts_without_rows(ff):
     """ff_render_distributed's messages (ff_dist_part_bytes): one per part that owns rows, at back-to-back offsets in rank 0's
     gather buffer; a part without rows sends nothing and rank 0 posts no receive for it - both sides apply the same predicate

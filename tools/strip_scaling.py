@@ -17,7 +17,7 @@ with lib.Tracer(0) as t:
     full = t.stats().kernel_ms
     print(f"1 rank : kernel {full:8.2f} ms")
     for n in ((8,) if os.environ.get("FF_ONLY8") else (2, 4, 8)):
-        rows = dist.strip_rows_for(n)
+        rows = int(os.environ["FF_STRIP_ROWS"]) if os.environ.get("FF_STRIP_ROWS") else dist.strip_rows_for(n)
         worst = 0.0
         times = []
         for part in range(n):
