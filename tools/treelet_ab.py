@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpupathtracer_amd import lib, scenes, types as T
 
+os.environ.setdefault("FF_NO_PRIMARY_CACHE", "1")  # (every timed frame pays for its own pre-pass)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 inside = scenes.posed_camera(1920, 1080, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
 which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["c2", "c3", "c4"]
