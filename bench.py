@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp-per-launch", type=int, default=0)
     ap.add_argument("--no-companion", action="store_true", help="skip the untimed default-camera frame")
+    ap.add_argument("--keep-primary-hits", action="store_true",
+                    help="let the library keep the pixels' stored primary hits from frame to frame (the viewer with its camera at rest); "
+                         "by default every timed frame pays for its own pre-pass")
     return ap.parse_args()
 
 
@@ -155,7 +158,8 @@ def main():
     args = parse_args()
     # Every timed frame does ALL its work: the library would otherwise keep the pixels' stored primary hits from one frame to the next
     # (same camera, same scene: a viewer at rest) and spare the later frames their 0.17 ms pre-pass.
-    os.environ.setdefault("FF_NO_PRIMARY_CACHE", "1")
+    if not args.keep_primary_hits:
+        os.environ.setdefault("FF_NO_PRIMARY_CACHE", "1")
     import torch
     import torch.distributed as dist
 
