@@ -359,7 +359,7 @@ struct Builder {
                     }
                 }
             }
-            return where;
+            return where >= 0 ? where : bn[0].left; // (boxes that are not numbers compare false with everything: any place is a valid place)
         };
         auto replace_child = [&](int p, int from, int to) {
             if (bn[p].left == from) bn[p].left = to;

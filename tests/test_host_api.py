@@ -125,6 +125,16 @@ def test_tree_optimiser_lowers_the_summed_box_area_and_keeps_the_tree_valid(ff, 
         assert many.bvh_child_area < one.bvh_child_area < 0.98 * off.bvh_child_area
     sphere = scenes.sphere_stress_scene(2)
     assert info(sphere, 0).bvh_child_area == info(sphere, 3).bvh_child_area
+    # vertices that are not numbers: the compiler's self-check says so (valid == 0); the optimiser's searches, whose comparisons
+    # are all false on such boxes, still end
+    rng = np.random.default_rng(3)
+    tri = np.zeros((200, 24), dtype=np.float32)
+    tri[:, :9] = rng.uniform(-1, 1, (200, 9))
+    tri[::7, 3] = np.nan
+    tri[::11, 0:9] = np.inf
+    red = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0))
+    broken = scenes.Scene().add_mesh(tri, bxdf=red).add_plane(bxdf=red).finalize()
+    assert info(broken, 4).valid == 0 and info(broken, 0).valid == 0
 
 
 def test_scene_compiler_edge_cases(ff):
