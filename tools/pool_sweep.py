@@ -99,7 +99,8 @@ def main():
                     touched.add(k)
             with lib.Tracer(0) as t:
                 t.upload_scene(scene)
-                t.render(cam, params, want_rgb8=False, want_radiance=False)  # warm-up
+                for _ in range(2 if a.keep_primary_hits else 1):  # warm-up (hits kept: a one-off frame, then the one that runs the last pre-pass)
+                    t.render(cam, params, want_rgb8=False, want_radiance=False)
                 if a.check and rep == 0:
                     _, rad = t.render(cam, params)
                     bits = rad.view(np.uint32).copy()
