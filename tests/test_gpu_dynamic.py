@@ -239,6 +239,51 @@ def test_collapse_rule_and_treelet_passes_change_the_tree_not_the_frame(monkeypa
         assert out["three_passes"][3] < out["no_treelets"][3], "treelet restructuring did not lower the node visits per ray"
 
 
+@pytest.mark.parametrize("builder", [T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC], ids=["lbvh_tree", "ploc_tree"])
+def test_parallel_reinsertion_changes_the_tree_not_the_frame(monkeypatch, builder):
+    """csrc/ff_build.hip reinsert_*_kernel (FF_GPU_REINSERT passes, four by default): nodes are taken out and put back where they add
+    the least surface area, many at a time (locks on the six nodes a move rewires, no move into another move's subtree).  Every
+    variant is a well-formed tree over the same leaves and renders the same bits; the passes lower the node visits per ray; a
+    mesh where every move conflicts with its neighbours' (a strip of identical triangles) and tiny meshes come through."""
+    scene = scenes.cornell_wahoo_scene()
+    cam = scenes.posed_camera(96, 72, position=(0.0, 0.0, 2.4), yaw=-90.0, pitch=0.0)
+    params = lib.render_params(96, 72, 6, 4, 9)
+    out = {}
+    for passes in ("0", None, "9"):
+        monkeypatch.delenv("FF_GPU_REINSERT", raising=False)
+        if passes is not None:
+            monkeypatch.setenv("FF_GPU_REINSERT", passes)
+        with lib.Tracer(0) as t:
+            t.set_builder(builder)
+            t.upload_scene(scene)
+            check_trees(t, len(scene))
+            t.set_collect_stats(True)
+            rgb8, rad = t.render(cam, params)
+            st = t.stats()
+            out[passes] = (rgb8, rad, st.nodes_visited / st.rays_traced, st.rays_traced)
+    for o in out.values():
+        assert np.array_equal(o[0], out["0"][0]) and same_bits(o[1], out["0"][1]) and o[3] == out["0"][3]
+    assert out["9"][2] <= out[None][2] * 1.01 and out[None][2] < out["0"][2], [o[2] for o in out.values()]
+    # degenerate inputs: 300 identical triangles, and meshes of 2 .. 9 triangles, with many passes
+    monkeypatch.setenv("FF_GPU_REINSERT", "16")
+    red = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0))
+    one = np.zeros((1, 24), dtype=np.float32)
+    one[0, :9] = [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    small = scenes.posed_camera(48, 36, position=(0.3, 0.3, 2.4), yaw=-90.0, pitch=0.0)
+    sp = lib.render_params(48, 36, 3, 2, 4)
+    for count in (300, 2, 3, 5, 9):
+        sc = scenes.Scene().add_mesh(np.repeat(one, count, axis=0), bxdf=red).add_plane((0, 0, -1), (0, 0, 0), (4, 4, 4), red).finalize()
+        with lib.Tracer(0) as t:
+            t.set_builder(builder)
+            t.upload_scene(sc)
+            check_trees(t, len(sc))
+            got = t.render(small, sp)
+            sp.trace_mode = T.TRACE_BRUTE_FORCE
+            ref = t.render(small, sp)
+            sp.trace_mode = T.TRACE_BVH
+            assert np.array_equal(got[0], ref[0]) and same_bits(got[1], ref[1]), count
+
+
 def test_host_built_tree_structure(tracer):
     scene = scenes.cornell_wahoo_scene()
     tracer.upload_scene(scene)
