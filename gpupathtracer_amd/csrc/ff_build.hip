@@ -1458,11 +1458,11 @@ int gpu_build_mesh(hipStream_t stream, BuildScratch& scratch, const FfTriangle* 
                                                               b.tables);
         }
     }
-    // Reinsertion passes (reinsert_find_kernel; FF_GPU_REINSERT: how many).  Four by default on both builders: same box, share of the
+    // Reinsertion passes (reinsert_find_kernel; FF_GPU_REINSERT: how many).  Eight by default for meshes of up to 65 536 triangles, four beyond, on both builders: same box, share of the
     // host tree's trace rate, LBVH 87 -> 95 % on C2 (8 passes: 97 %, where it saturates), 86 -> 90-94 % on C3, 90 -> 95 % on the
     // 983 040-triangle sphere; PLOC 91 -> 93 %, 90 -> 95 %, 90 -> 93 %; a pass costs 0.18 ms on 5 172 triangles, 1.25 ms on 983 040
     // (profiles/r04_r_*).
-    int reinsert = 4;
+    int reinsert = T <= 65536 ? 8 : 4; // (small meshes: where the gain saturates, 0.18 ms a pass)
     if (const char* e = std::getenv("FF_GPU_REINSERT")) reinsert = std::max(0, std::min(64, std::atoi(e)));
     if (reinsert > 0 && T >= 8) {
         if (!ploc && passes == 0) sizes_from_ranges_kernel<<<node_grid, kBuildBlock, 0, stream>>>(T, b.first, b.last, b.sizes);

@@ -241,7 +241,7 @@ def test_collapse_rule_and_treelet_passes_change_the_tree_not_the_frame(monkeypa
 
 @pytest.mark.parametrize("builder", [T.BUILD_GPU_LBVH, T.BUILD_GPU_PLOC], ids=["lbvh_tree", "ploc_tree"])
 def test_parallel_reinsertion_changes_the_tree_not_the_frame(monkeypatch, builder):
-    """csrc/ff_build.hip reinsert_*_kernel (FF_GPU_REINSERT passes, four by default): nodes are taken out and put back where they add
+    """csrc/ff_build.hip reinsert_*_kernel (FF_GPU_REINSERT passes, eight by default on meshes of up to 65 536 triangles, four beyond): nodes are taken out and put back where they add
     the least surface area, many at a time (locks on the six nodes a move rewires, no move into another move's subtree).  Every
     variant is a well-formed tree over the same leaves and renders the same bits; the passes lower the node visits per ray; a
     mesh where every move conflicts with its neighbours' (a strip of identical triangles) and tiny meshes come through."""

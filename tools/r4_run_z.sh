@@ -1,5 +1,3 @@
 #!/bin/bash
 OUT=gpurun_out/${1:-r4z}; mkdir -p $OUT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo rc=$? >> $OUT/pytest_gpu.log; tail -6 $OUT/pytest_gpu.log | cut -c1-300
-grep -q "rc=0" $OUT/pytest_gpu.log || exit 1
-timeout -k 10 600 python tools/build_bench.py > $OUT/build_bench.txt 2>&1; tail -30 $OUT/build_bench.txt | cut -c1-220
+for tp in 0 1 2; do echo "# FF_TREELET_PASSES=$tp" | tee -a $OUT/reinsert_vs_treelet.txt; FF_TREELET_PASSES=$tp timeout -k 10 300 python tools/reinsert_ab.py 32 c2,c4 0,4,8 2>&1 | grep "lbvh" | cut -c1-200 | tee -a $OUT/reinsert_vs_treelet.txt; done
