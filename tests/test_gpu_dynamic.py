@@ -264,6 +264,20 @@ def test_parallel_reinsertion_changes_the_tree_not_the_frame(monkeypatch, builde
     for o in out.values():
         assert np.array_equal(o[0], out["0"][0]) and same_bits(o[1], out["0"][1]) and o[3] == out["0"][3]
     assert out["9"][2] <= out[None][2] * 1.01 and out[None][2] < out["0"][2], [o[2] for o in out.values()]
+    # the passes do not depend on the run - which of two conflicting moves wins is decided by (gain, node), not by who came first:
+    # two builds walk the same number of nodes and test the same number of triangles for the same frame
+    monkeypatch.delenv("FF_GPU_REINSERT", raising=False)
+    twice = []
+    for _ in range(2):
+        with lib.Tracer(0) as t:
+            t.set_builder(builder)
+            t.upload_scene(scene)
+            t.set_collect_stats(True)
+            t.render(cam, params)
+            st = t.stats()
+            twice.append((st.nodes_visited, st.tris_tested, st.scene_bytes_nodes))
+    if builder == T.BUILD_GPU_LBVH:  # (PLOC numbers its nodes in the order its merges happen to finish: same clusters, another numbering, other ties)
+        assert twice[0] == twice[1]
     # degenerate inputs: 300 identical triangles, and meshes of 2 .. 9 triangles, with many passes
     monkeypatch.setenv("FF_GPU_REINSERT", "16")
     red = scenes.make_bxdf(T.BXDF_DIFFUSE, albedo=(1, 0, 0))
