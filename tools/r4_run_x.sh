@@ -1,7 +1,5 @@
 #!/bin/bash
 OUT=gpurun_out/${1:-r4x}; mkdir -p $OUT
-for spp in 1 2 4; do
-echo "# default camera, $spp spp, kept / one-off" | tee -a $OUT/knobs_1spp_d.log
-timeout -k 5 600 python tools/pool_sweep.py --keep-primary-hits --camera default --scene c2 --spp $spp --reps 9 "FF_QUEUE_TAIL=8" "FF_QUEUE_TAIL=64" "FF_QUEUE_TAIL=24" 2>&1 | grep -v "^  rep\|check \[" | cut -c1-200 | tee -a $OUT/knobs_1spp_d.log
-timeout -k 5 600 python tools/pool_sweep.py --camera default --scene c2 --spp $spp --reps 9 "FF_QUEUE_TAIL=8" "FF_QUEUE_TAIL=64" "FF_QUEUE_TAIL=24" 2>&1 | grep -v "^  rep\|check \[" | cut -c1-200 | tee -a $OUT/knobs_1spp_d.log
+for spec in "c2 1024 default" "c3 4096 inside" "c3 1024 inside"; do set -- $spec
+  timeout -k 5 600 python tools/pool_sweep.py --check --scene $1 --spp $2 --camera $3 --reps 3 "FF_DUMMY=1" "FF_TAIL_GROUP=16" "FF_TAIL_GROUP=16,FF_TAIL_BLOCKS=2" "FF_TAIL_GROUP=8,FF_TAIL_BLOCKS=2" "FF_TAIL_GROUP=8,FF_TAIL_BLOCKS=3" 2>&1 | grep -v "^  rep\|check \[" | cut -c1-200 | tee -a $OUT/ab_tail_culled.log
 done
